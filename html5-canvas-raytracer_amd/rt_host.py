@@ -1,0 +1,237 @@
+"""Python host side of the MI355X ray-sphere path: scene loading/flattening and the ctypes
+binding of the C ABI in include/rt_hip.h.
+
+This mirrors what the Node host (js/index.js + napi/rt_napi.cc) does, for the Python callers
+the build contract requires (pytest, bench.py, __graft_entry__).  It contains NO rendering
+code and no CPU fallback: every render goes through librt_hip.so -> the HIP kernel, and
+`load_library()` raises if that library is missing.
+
+Scene schema = the reference's locals/literals (main.js:85-163, :194, :283-284), see
+js/scene.js; blob layout = include/rt_hip.h (rt_scene_header + tables).
+"""
+import base64
+import ctypes as C
+import json
+import os
+import struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SCENES_DIR = os.path.join(HERE, "scenes")
+LIB_PATH = os.path.join(HERE, "csrc", "librt_hip.so")
+
+RT_SCENE_MAGIC = 0x31535452
+RT_ABI_VERSION = 1
+HEADER_BYTES, SPHERE_BYTES, TEXDESC_BYTES = 208, 192, 16
+SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER = 0, 1, 2
+
+RT_FLAG_COUNT = 1
+RT_FLAG_STRICT_FP = 2
+
+
+# --------------------------------------------------------------------------- scenes
+def load_scene(name_or_path):
+    """Load a scene JSON written by js/flatten.js sceneToJSON (textures resolved to bytes)."""
+    path = name_or_path
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = os.path.join(SCENES_DIR, name_or_path + ".json")
+    with open(path) as f:
+        scene = json.load(f)
+    d = os.path.dirname(os.path.abspath(path))
+    for t in scene["textures"]:
+        if "base64" in t:
+            t["texels"] = base64.b64decode(t.pop("base64"))
+        else:
+            with open(os.path.join(d, t["file"]), "rb") as f:
+                t["texels"] = f.read()
+        if len(t["texels"]) != t["width"] * t["height"] * 4:
+            raise ValueError("texture is not width*height*4 bytes of RGBA8")
+    return scene
+
+
+def validate_scene(scene):
+    """Host-side checks, same rules as js/scene.js validateScene."""
+    cam = scene["camera"]
+    for k in ("origin", "axisX", "axisY", "axisZ"):
+        if len(cam[k]) != 3:
+            raise ValueError("scene.camera.%s must be a 3-vector" % k)
+    if not (isinstance(scene["segs"], int) and 0 <= scene["segs"] <= 16):
+        raise ValueError("scene.segs must be an integer in [0,16]")
+    if scene.get("supersample", 1) not in (1, 2):
+        raise ValueError("scene.supersample must be 1 or 2")
+    if not (1 <= len(scene["objects"]) <= 256):
+        raise ValueError("scene.objects must hold 1..256 spheres")
+    if len(scene["lights"]) > 16:
+        raise ValueError("scene.lights must hold 0..16 lights")
+    for i, o in enumerate(scene["objects"]):
+        s = o["mtl"]["sampler"]
+        if s["kind"] not in (SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER):
+            raise ValueError("object %d: unsupported sampler kind (the Math.random stars sampler "
+                             "of main.js:135-139 is not supported)" % i)
+        if s["kind"] == SAMPLER_TEXTURE and not (0 <= s["texture"] < len(scene["textures"])):
+            raise ValueError("object %d: texture index out of range" % i)
+
+
+def flatten_scene(scene):
+    """scene dict -> pointer-free blob (bytes), byte-identical to js/flatten.js flattenScene."""
+    validate_scene(scene)
+    objs, lights, texs = scene["objects"], scene["lights"], scene["textures"]
+    objects_off = HEADER_BYTES
+    lights_off = objects_off + len(objs) * SPHERE_BYTES
+    tex_off = lights_off + len(lights) * 24
+    cursor = tex_off + len(texs) * TEXDESC_BYTES
+    texel_off = []
+    for t in texs:
+        texel_off.append(cursor)
+        cursor += (len(t["texels"]) + 7) & ~7
+    total = cursor
+    cam = scene["camera"]
+    out = bytearray(total)
+    hdr = struct.pack(
+        "<IIQ12d3d3dIIIIIIQQQ", RT_SCENE_MAGIC, RT_ABI_VERSION, total,
+        *cam["origin"], *cam["axisX"], *cam["axisY"], *cam["axisZ"],
+        float(scene.get("fovDeg", 60)), float(scene.get("light_intensity", 50)), float(scene.get("epsilon", 0.001)),
+        *[float(x) for x in scene.get("miss_color", [1, 0, 0])],
+        scene["segs"], scene.get("supersample", 1), len(objs), len(lights), len(texs), 0,
+        objects_off, lights_off, tex_off)
+    assert len(hdr) == HEADER_BYTES
+    out[0:HEADER_BYTES] = hdr
+    o = objects_off
+    for ob in objs:
+        m = ob["mtl"]
+        s = m["sampler"]
+        if s["kind"] == SAMPLER_CHECKER:
+            ck = [s["freqU"], s["freqV"], *s["colors"][0], *s["colors"][1]]
+        else:
+            ck = [0.0] * 8
+        rec = struct.pack("<22d2id", *ob["origin"], ob["r2"], *m["color"], m["specular_exponent"],
+                          *m["albedo"], m["refract_index"], *[float(x) for x in ck],
+                          s["kind"], s["texture"] if s["kind"] == SAMPLER_TEXTURE else -1, 0.0)
+        assert len(rec) == SPHERE_BYTES
+        out[o:o + SPHERE_BYTES] = rec
+        o += SPHERE_BYTES
+    for l in lights:
+        out[o:o + 24] = struct.pack("<3d", *l)
+        o += 24
+    for t, off in zip(texs, texel_off):
+        out[o:o + TEXDESC_BYTES] = struct.pack("<IIQ", t["width"], t["height"], off)
+        o += TEXDESC_BYTES
+    for t, off in zip(texs, texel_off):
+        out[off:off + len(t["texels"])] = t["texels"]
+    return bytes(out)
+
+
+# --------------------------------------------------------------------------- C ABI binding
+class RtTiles(C.Structure):
+    _fields_ = [("tile_rows", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32), ("n_tiles", C.c_uint32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("pixels", C.c_uint64), ("rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("sphere_tests", C.c_uint64)]
+
+
+# every symbol include/rt_hip.h declares: (restype, argtypes)
+ABI = {
+    "rt_init": (C.c_int, [C.c_int]),
+    "rt_shutdown": (None, []),
+    "rt_device_count": (C.c_int, []),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_abi_version": (C.c_uint32, []),
+    "rt_scene_validate": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_scene_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rt_scene_free": (None, [C.c_void_p]),
+    "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.POINTER(RtStats)]),
+    "rt_render": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
+    "rt_alloc_pinned": (C.c_void_p, [C.c_size_t]),
+    "rt_free_pinned": (None, [C.c_void_p]),
+    "rt_alloc_device": (C.c_void_p, [C.c_int, C.c_size_t]),
+    "rt_free_device": (None, [C.c_int, C.c_void_p]),
+    "rt_copy_to_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rt_deinterleave_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint64, C.c_void_p]),
+}
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen librt_hip.so and type every entry point.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RtError("HIP library %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                      "there is no CPU fallback for the render path" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)        # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.rt_last_error()
+        raise RtError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+class Renderer:
+    """A scene resident on one GPU.  render_tiles() writes into caller-provided DEVICE memory
+    (a torch uint8 CUDA tensor's data_ptr, or rt_alloc_device memory)."""
+
+    def __init__(self, scene, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.blob = scene if isinstance(scene, (bytes, bytearray)) else flatten_scene(scene)
+        self.device = device
+        _check(self.lib, self.lib.rt_init(0), "rt_init")
+        h = C.c_void_p()
+        buf = C.create_string_buffer(self.blob, len(self.blob))
+        _check(self.lib, self.lib.rt_scene_upload(device, buf, len(self.blob), C.byref(h)), "rt_scene_upload")
+        self.handle = h
+
+    def render_tiles(self, w, h, d_out, tiles=None, stream=None, flags=0, want_stats=False):
+        t = tiles if isinstance(tiles, RtTiles) else RtTiles(*(tiles or (h, 0, 1, 1)))
+        st = RtStats() if want_stats else None
+        rc = self.lib.rt_render_tiles_device(self.handle, w, h, C.byref(t), C.c_void_p(d_out), C.c_void_p(stream or 0),
+                                             flags, C.byref(st) if st is not None else None)
+        _check(self.lib, rc, "rt_render_tiles_device")
+        return st
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render(width, height, scene, flags=0, lib=None):
+    """render(width,height,scene) -> (bytes RGBA8, RtStats): the whole-frame entry point, host buffer out."""
+    lib = lib or load_library()
+    blob = scene if isinstance(scene, (bytes, bytearray)) else flatten_scene(scene)
+    _check(lib, lib.rt_init(0), "rt_init")
+    n = width * height * 4
+    p = lib.rt_alloc_pinned(n)
+    if not p:
+        raise RtError("rt_alloc_pinned(%d) failed: %s" % (n, lib.rt_last_error().decode()))
+    try:
+        st = RtStats()
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(lib, lib.rt_render(buf, len(blob), width, height, C.c_void_p(p), flags, C.byref(st)), "rt_render")
+        return C.string_at(p, n), st
+    finally:
+        lib.rt_free_pinned(p)

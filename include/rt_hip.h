@@ -1,0 +1,178 @@
+/*
+ * rt_hip.h — C ABI of the MI355X ray-sphere trace/shade path.
+ *
+ * This is the drop-in boundary for ONE path of termuxinator/html5-canvas-raytracer:
+ * the per-pixel loop of main.js (primary-ray generation :184-193, intersectWorld
+ * :220-337, intersectSphere :420-451, samplers :126-133/:343-351/:404, RGBA8 store
+ * :195-198).  The reference has no FFI of its own; the entry points
+ * below are what a Node N-API / Python ctypes binding for that path binds to.  Each
+ * comment names the reference construct the entry point or field replaces.
+ *
+ * Plain C types only.  No torch, no C++ across the ABI.  All functions return 0 on
+ * success and a negative rt_status on failure; rt_last_error() describes the failure
+ * of the calling thread's last call.
+ *
+ * The scene crosses the boundary as ONE contiguous, pointer-free blob
+ * (rt_scene_header followed by the tables it gives offsets to), so any host language
+ * can build it with typed arrays and the library can upload it with one copy.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+#define RT_SCENE_MAGIC 0x31535452u /* "RTS1" little endian */
+
+#define RT_MAX_OBJECTS  256u
+#define RT_MAX_LIGHTS   16u
+#define RT_MAX_TEXTURES 16u
+#define RT_MAX_SEGS     16u
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,     /* malformed scene blob / bad argument */
+  RT_ERR_UNSUPPORTED = -2, /* e.g. sampler kind 3 (Math.random stars, main.js:135-139) */
+  RT_ERR_DEVICE = -3,      /* HIP / RCCL failure, or no GPU */
+  RT_ERR_NOMEM = -4,
+  RT_ERR_STATE = -5        /* rt_init not called, bad handle */
+} rt_status;
+
+/* mtl.sampler closures of the reference, enumerated */
+enum {
+  RT_SAMPLER_COLOR = 0,   /* main.js:404       constant mtl.color                 */
+  RT_SAMPLER_TEXTURE = 1, /* main.js:143-145   sampleTexture(tex, hit.u, hit.v)   */
+  RT_SAMPLER_CHECKER = 2  /* main.js:126-133   sphere checker on its own u,v      */
+};
+
+/* One sphere + its material: createSphere (main.js:408-418) + createMaterial (:397-406).
+ * 24 doubles = 192 bytes. */
+typedef struct rt_sphere {
+  double origin[3];           /* obj.origin            main.js:411 */
+  double r2;                  /* obj.r2                main.js:413 */
+  double color[3];            /* mtl.color             main.js:399 */
+  double specular_exponent;   /* mtl.specular_exponent main.js:401 */
+  double albedo[5];           /* ambient,diffuse,specular,reflect,refract  main.js:400 */
+  double refract_index;       /* mtl.refract_index     main.js:402 */
+  double checker_freq[2];     /* the literals 5000, 2500 of main.js:129-130 */
+  double checker_color[2][3]; /* the table of main.js:131 */
+  int32_t sampler_kind;       /* RT_SAMPLER_* */
+  int32_t texture;            /* index into the texture table for RT_SAMPLER_TEXTURE, else -1 */
+  double reserved;
+} rt_sphere;
+
+/* createTexture (main.js:339-341); texels are RGBA8 rows, top row first (getImageData layout, :388-391) */
+typedef struct rt_texture_desc {
+  uint32_t width;
+  uint32_t height;
+  uint64_t texels_offset; /* bytes from blob start to width*height*4 bytes */
+} rt_texture_desc;
+
+typedef struct rt_scene_header {
+  uint32_t magic;          /* RT_SCENE_MAGIC */
+  uint32_t abi_version;    /* RT_ABI_VERSION */
+  uint64_t total_bytes;    /* size of the whole blob */
+  double cam_origin[3];    /* origin  main.js:85,93 */
+  double cam_axis_x[3];    /* axisX   main.js:86,97 */
+  double cam_axis_y[3];    /* axisY   main.js:87,98 */
+  double cam_axis_z[3];    /* axisZ   main.js:88,99 */
+  double fov_deg;          /* 60      main.js:102 */
+  double light_intensity;  /* 50      main.js:284 (shared across lights, quirk q2) */
+  double epsilon;          /* 0.001   main.js:430-436,445 */
+  double miss_color[3];    /* [1,0,0] main.js:231 */
+  uint32_t segs;           /* 8       main.js:194 */
+  uint32_t supersample;    /* 1, or 2 = render 2w x 2h and box-average 2x2 with (a+b+c+d+2)>>2 (cfg5) */
+  uint32_t n_objects;      /* objs.length, already in the reference's sorted order (main.js:159-163) */
+  uint32_t n_lights;       /* lights.length main.js:283 */
+  uint32_t n_textures;
+  uint32_t reserved0;
+  uint64_t objects_offset;  /* rt_sphere[n_objects] */
+  uint64_t lights_offset;   /* double[3*n_lights] */
+  uint64_t textures_offset; /* rt_texture_desc[n_textures] */
+} rt_scene_header;
+
+/* Which rows of the w x h frame a call renders, as row tiles dealt round-robin:
+ * tile t (t = tile_first + i*tile_stride, i in [0,n_tiles)) covers frame rows
+ * [t*tile_rows, min(h,(t+1)*tile_rows)) and is stored at out + i*tile_rows*w*4.
+ * The whole frame is {tile_rows=h, tile_first=0, tile_stride=1, n_tiles=1}.
+ * Replaces the scanline scheduler spanish(y) (main.js:183-201). */
+typedef struct rt_tiles {
+  uint32_t tile_rows;
+  uint32_t tile_first;
+  uint32_t tile_stride;
+  uint32_t n_tiles;
+} rt_tiles;
+
+/* Per-render counters and timings; counters are filled only when RT_FLAG_COUNT is set
+ * (they come from an instrumented kernel variant, never from the timed one). */
+typedef struct rt_stats {
+  double kernel_ms;        /* hipEvent time of the trace kernel(s) on the render stream */
+  double total_ms;         /* host wall time of the call */
+  uint64_t pixels;         /* output pixels written */
+  uint64_t rays;           /* intersectWorld invocations with segs>0 (main.js:220-221) */
+  uint64_t shadow_rays;    /* lights tested for occlusion (main.js:293-304) */
+  uint64_t sphere_tests;   /* intersectSphere calls (main.js:228,296) */
+} rt_stats;
+
+enum {
+  RT_FLAG_NONE = 0,
+  RT_FLAG_COUNT = 1,        /* run the counting variant and fill rays/shadow_rays/sphere_tests */
+  RT_FLAG_STRICT_FP = 2     /* no FMA contraction: operation-for-operation with the JS expression trees */
+};
+
+typedef struct rt_scene_dev rt_scene_dev; /* opaque: a scene resident in one GPU's HBM */
+
+/* Library lifetime.  rt_init(max_devices): use up to max_devices GPUs (0 = all visible). */
+int rt_init(int max_devices);
+void rt_shutdown(void);
+int rt_device_count(void);            /* GPUs in use after rt_init, or a negative rt_status */
+const char *rt_last_error(void);
+uint32_t rt_abi_version(void);
+
+/* Validate a scene blob without touching a GPU (host logic; usable in CPU-only tests). */
+int rt_scene_validate(const void *scene_blob, size_t blob_bytes);
+
+/* Upload a scene to `device` (index into the GPUs in use) and keep it resident. */
+int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_scene_dev **out);
+void rt_scene_free(rt_scene_dev *scene);
+
+/* Render tiles of the w x h frame into DEVICE memory `d_out_rgba` (at least
+ * n_tiles*tile_rows*w*4 bytes) on `hip_stream` (a hipStream_t; NULL = the library's own
+ * stream for that device).  Asynchronous unless `stats` is non-NULL (then it waits and
+ * times).  This is the per-pixel loop main.js:185-199 for those rows. */
+int rt_render_tiles_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles,
+                           void *d_out_rgba, void *hip_stream, uint32_t flags, rt_stats *stats);
+
+/* render(width,height,scene): whole frame into HOST memory (any host pointer; memory from
+ * rt_alloc_pinned makes the copy-out DMA directly).  With more than one GPU in use the
+ * frame is sharded by interleaved row tiles and reassembled on GPU 0 with one RCCL gather
+ * before the copy-out.  Replaces redraw()/spanish() + ImageData (main.js:83,180-201). */
+int rt_render(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h,
+              uint8_t *out_rgba, uint32_t flags, rt_stats *stats);
+
+/* Pinned host framebuffers (the ImageData buffer of main.js:83 becomes one of these). */
+void *rt_alloc_pinned(size_t bytes);
+void rt_free_pinned(void *p);
+
+/* Device scratch helpers for hosts without their own allocator (the Python/torch host
+ * passes torch storage instead and never calls these). */
+void *rt_alloc_device(int device, size_t bytes);
+void rt_free_device(int device, void *p);
+int rt_copy_to_host(int device, void *dst_host, const void *src_device, size_t bytes);
+
+/* De-interleave a gathered frame: src holds, for rank g in [0,n_ranks), that rank's tiles
+ * (g, g+n_ranks, ...) contiguously with `rank_stride_bytes` between ranks; dst receives the
+ * frame in row order.  One HBM->HBM pass on `hip_stream`. */
+int rt_deinterleave_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h,
+                           uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_bytes,
+                           void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

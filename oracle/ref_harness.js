@@ -1,0 +1,177 @@
+'use strict';
+// ORACLE / TEST INFRASTRUCTURE — never imported by the product path.
+//
+// Loads the UNMODIFIED reference script from /root/reference/main.js (read at run time,
+// never copied) inside ~60 lines of DOM stubs and exposes two ways of running it:
+//
+//   runMain(w, h)                  the reference's own main(): its 14-sphere scene, depth 8
+//                                  (main.js:77-214), timers drained synchronously;
+//   renderScene(scene, w, h)       any scene of OUR schema driven through the reference's
+//                                  own intersectWorld (main.js:220) with objects built by the
+//                                  reference's createSphere/createMaterial.
+//
+// Controls (SURVEY.md §8(c)): Math.random is pinned to 0.5 while the reference runs
+// (stars sampler main.js:135-139 => black).  The lights and their intensity are literals
+// inside intersectWorld (main.js:283-284); a scene with other lights is served by an
+// in-memory substitution of exactly those two lines (asserted to match first; nothing is
+// written to disk).  Exists only in the build container: the GPU box has no /root/reference.
+
+const fs = require('fs');
+const path = require('path');
+const {readPNG} = require('../html5-canvas-raytracer_amd/js/png.js');
+
+const REF_DIR = process.env.RT_REFERENCE_DIR || '/root/reference';
+const LIGHTS_LINE = 'const lights = [[5.0,10.0,5.0],[5.0,10.0,0.0]/*,[0.0,7.5,0.0],[-5.0,10.0,0.0]*/];';
+const INTENSITY_LINE = 'let light_intensity = 50; // common (for now)';
+
+function available() { return fs.existsSync(path.join(REF_DIR, 'main.js')); }
+
+function jsLiteral(x) {           // exact double -> source text
+  if (Array.isArray(x)) return '[' + x.map(jsLiteral).join(',') + ']';
+  if (Object.is(x, -0)) return '-0';
+  return String(x);               // JS shortest round-trip repr
+}
+
+function loadReference(opts) {
+  opts = opts || {};
+  let src = fs.readFileSync(path.join(REF_DIR, 'main.js'), 'utf8');
+  if (opts.lights || opts.light_intensity !== undefined) {
+    if (!src.includes(LIGHTS_LINE) || !src.includes(INTENSITY_LINE)) throw new Error('oracle: light literals not found in reference');
+    if (opts.lights) src = src.replace(LIGHTS_LINE, 'const lights = ' + jsLiteral(opts.lights) + ';');
+    if (opts.light_intensity !== undefined) src = src.replace(INTENSITY_LINE, 'let light_intensity = ' + jsLiteral(opts.light_intensity) + ';');
+  }
+
+  const timers = [];
+  const state = {width: 0, height: 0, frame: null};
+  const makeCanvas = () => {
+    const canvas = {width: 0, height: 0, _image: null};
+    canvas.getContext = () => ({
+      createImageData: (w, h) => { const d = {width: w, height: h, data: new Uint8ClampedArray(w * h * 4)}; state.frame = d; return d; },
+      putImageData: () => {},
+      fillText: () => {},
+      drawImage: (img) => { canvas._image = img; },
+      getImageData: () => ({data: new Uint8ClampedArray(canvas._image._rgba)}),
+    });
+    return canvas;
+  };
+  const mainCanvas = makeCanvas();
+  const body = {appendChild: () => {}, onload: null, get clientWidth() { return state.width; }, get clientHeight() { return state.height; }};
+  const document = {
+    body,
+    createElement: (tag) => (tag === 'canvas' ? makeCanvas() : {innerHTML: ''}),
+    getElementById: () => mainCanvas,
+  };
+  const window = {onerror: null};
+  const consoleStub = {log: () => {}};
+  function Image() { this.onload = null; this.width = 0; this.height = 0; this._rgba = null; }
+  Object.defineProperty(Image.prototype, 'src', {
+    set: function (s) {
+      const img = readPNG(path.join(REF_DIR, s));
+      this.width = img.width; this.height = img.height; this._rgba = img.data;
+      timers.push(() => this.onload({target: this}));
+    },
+  });
+  const setTimeoutStub = (fn, ms, ...args) => { timers.push(() => fn(...args)); };
+
+  const exportsList = 'intersectWorld,intersectSphere,createSphere,createMaterial,createTexture,checkerTexture,sampleTexture,main';
+  const factory = new Function('document', 'window', 'Image', 'console', 'setTimeout', src + '\n;return {' + exportsList + '};');
+  const ref = factory(document, window, Image, consoleStub, setTimeoutStub);
+  const drain = () => { while (timers.length) timers.shift()(); };
+  return {ref, state, drain};
+}
+
+function withPinnedRandom(fn) {
+  const saved = Math.random;
+  Math.random = () => 0.5;
+  try { return fn(); } finally { Math.random = saved; }
+}
+
+// The reference's own frame (main.js:77-214) at w x h.
+function runMain(w, h) {
+  const L = loadReference();
+  L.state.width = w; L.state.height = h;
+  return withPinnedRandom(() => { L.ref.main(); L.drain(); return new Uint8Array(L.state.frame.data.buffer); });
+}
+
+// Build reference-side objects for one of OUR scenes; samplers are closures over the
+// reference's own sampleTexture / the checker expression of main.js:126-133 with its literals
+// as parameters (the literal form itself is covered by runMain).
+function buildRefObjects(ref, scene) {
+  const textures = scene.textures.map((t) => ({width: t.width, height: t.height, texels: new Uint8ClampedArray(t.texels), loaded: true}));
+  return scene.objects.map((o) => {
+    const m = o.mtl;
+    const mtl = ref.createMaterial(m.color.slice(), m.albedo.slice(), m.specular_exponent, m.refract_index);
+    const sphere = ref.createSphere(o.origin.slice(), 0, mtl);
+    sphere.r2 = o.r2;
+    sphere.surface_area = 4 * Math.PI * o.r2;
+    const s = m.sampler;
+    if (s.kind === 1) {
+      const tex = textures[s.texture];
+      mtl.sampler = (hit) => ref.sampleTexture(tex, hit.u, hit.v);
+    } else if (s.kind === 2) {
+      const fu = s.freqU, fv = s.freqV, table = s.colors;
+      mtl.sampler = (hit) => {
+        const u = Math.atan2(-hit.n[1], -hit.n[0]) / Math.PI / 2 + 0.5;
+        const v = Math.asin(-hit.n[2]) / (Math.PI / 2) / 2 + 0.5;
+        return table[((u * fu) & 1) ^ ((v * fv) & 1)];
+      };
+    } else if (s.kind !== 0) throw new Error('oracle: unsupported sampler');
+    return sphere;
+  });
+}
+
+function sameLights(scene) {
+  const d = [[5.0, 10.0, 5.0], [5.0, 10.0, 0.0]];
+  return scene.light_intensity === 50 && JSON.stringify(scene.lights) === JSON.stringify(d);
+}
+
+// Drive the reference's intersectWorld over rows [row0,row1) of a w x h frame of `scene`.
+// Ray generation restates main.js:186-193 (validated bit-exact against runMain by the tests);
+// the byte conversion is a real Uint8ClampedArray store, as in main.js:195-198.
+// opts.count: also return the number of intersectWorld invocations with segs>0.
+function renderScene(scene, w, h, opts) {
+  opts = opts || {};
+  if ((scene.supersample || 1) !== 1) throw new Error('oracle: render supersampled scenes at 2w x 2h and box-filter (boxFilter2)');
+  if (scene.epsilon !== 0.001) throw new Error('oracle: the reference epsilon is the literal 0.001');
+  const L = loadReference(sameLights(scene) ? {} : {lights: scene.lights, light_intensity: scene.light_intensity});
+  const ref = L.ref;
+  const objects = buildRefObjects(ref, scene);
+  const row0 = opts.row0 || 0, row1 = opts.row1 === undefined ? h : opts.row1;
+  const out = new Uint8ClampedArray((row1 - row0) * w * 4);
+  const cam = scene.camera, origin = cam.origin, ax = cam.axisX, ay = cam.axisY, az = cam.axisZ;
+  const projA = scene.fovDeg * Math.PI / 180, projW = w / 2, projH = h / 2, projD = projW / Math.tan(projA / 2);
+  let rays = 0;
+  let iw = ref.intersectWorld;
+  return withPinnedRandom(() => {
+    let i = 0;
+    for (let y = row0; y < row1; y++) {
+      for (let x = 0; x < w; x++) {
+        const dist = [x - projW + 0.5, projH - y - 0.5, projD];
+        const target = [
+          origin[0] + ax[0] * dist[0] + ay[0] * dist[0] + az[0] * dist[0],
+          origin[1] + ax[1] * dist[1] + ay[1] * dist[1] + az[1] * dist[1],
+          origin[2] + ax[2] * dist[2] + ay[2] * dist[2] + az[2] * dist[2]];
+        let ray = [target[0] - origin[0], target[1] - origin[1], target[2] - origin[2]];
+        const l = Math.sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        if (l !== 0) { const s = 1 / l; ray = [ray[0] * s, ray[1] * s, ray[2] * s]; }
+        const rgb = iw(scene.segs, objects, origin, ray);
+        out[i++] = 255 * rgb[0]; out[i++] = 255 * rgb[1]; out[i++] = 255 * rgb[2]; out[i++] = 255;
+      }
+    }
+    return {rgba: new Uint8Array(out.buffer), rays};
+  });
+}
+
+// cfg5's 4x supersample, defined in SURVEY.md §8(d): average each 2x2 block of RGBA8 with (a+b+c+d+2)>>2.
+function boxFilter2(rgba, w2, h2) {
+  const w = w2 >> 1, h = h2 >> 1;
+  const out = new Uint8Array(w * h * 4);
+  for (let y = 0; y < h; y++) for (let x = 0; x < w; x++) for (let c = 0; c < 4; c++) {
+    const a = rgba[((2 * y) * w2 + 2 * x) * 4 + c], b = rgba[((2 * y) * w2 + 2 * x + 1) * 4 + c];
+    const d = rgba[((2 * y + 1) * w2 + 2 * x) * 4 + c], e = rgba[((2 * y + 1) * w2 + 2 * x + 1) * 4 + c];
+    out[(y * w + x) * 4 + c] = (a + b + d + e + 2) >> 2;
+  }
+  return out;
+}
+
+module.exports = {available, loadReference, runMain, renderScene, boxFilter2, REF_DIR};

@@ -1,0 +1,233 @@
+'use strict';
+// ORACLE / TEST INFRASTRUCTURE — CPU restatement #1 (JavaScript) of the hot path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may run this file;
+// the product path (html5-canvas-raytracer_amd/js/index.js -> N-API -> HIP) never does.
+//
+// render(w, h, scene, opts) restates, operation for operation and in the same order,
+//   main.js:184-199  per-pixel ray generation + RGBA8 store      (A1, A10)
+//   main.js:220-337  intersectWorld                               (A3-A9)
+//   main.js:420-451  intersectSphere                              (A2)
+//   main.js:126-133, 343-351, 404  the three enumerated samplers  (A8)
+// flat and allocation-free, so that it is BIT-IDENTICAL to the reference under the same
+// JS engine (pinned by tests/test_oracle_vs_reference.py via SHA-256 against main.js itself)
+// and fast enough to be the single-thread CPU baseline on the GPU box.
+//
+// Parity status: PINNED — against /root/reference/main.js executed in the build container
+// (oracle/ref_harness.js) and against the committed golden frames in tests/golden/.
+
+const INF = Infinity;
+
+function render(w, h, scene, opts) {
+  opts = opts || {};
+  const ss = scene.supersample || 1;
+  const row0 = opts.row0 || 0, row1 = opts.row1 === undefined ? h : opts.row1;
+  if (opts.rows) {                                   // explicit list of frame rows (bench sampling)
+    if (ss !== 1) throw new Error('restate: opts.rows needs supersample 1');
+    return renderPlain(w, h, scene, 0, 0, opts.rows);
+  }
+  if (ss === 1) return renderPlain(w, h, scene, row0, row1);
+  // cfg5 supersample: 2w x 2h by the reference rule, then (a+b+c+d+2)>>2 per channel
+  const hi = renderPlain(2 * w, 2 * h, scene, 2 * row0, 2 * row1);
+  const src = hi.rgba, w2 = 2 * w, rows = row1 - row0;
+  const out = new Uint8Array(rows * w * 4);
+  for (let y = 0; y < rows; y++) for (let x = 0; x < w; x++) for (let c = 0; c < 4; c++) {
+    const i = ((2 * y) * w2 + 2 * x) * 4 + c;
+    out[(y * w + x) * 4 + c] = (src[i] + src[i + 4] + src[i + w2 * 4] + src[i + w2 * 4 + 4] + 2) >> 2;
+  }
+  hi.rgba = out; hi.pixels = rows * w;
+  return hi;
+}
+
+function renderPlain(w, h, scene, row0, row1, rowList) {
+  if (!rowList) { rowList = []; for (let y = row0; y < row1; y++) rowList.push(y); }
+  const nRows = rowList.length;
+  const N = scene.objects.length, NL = scene.lights.length;
+  const EPS = scene.epsilon, LI0 = scene.light_intensity, SEGS = scene.segs;
+  const MISS = scene.miss_color || [1, 0, 0];                     // main.js:231
+  const PI = Math.PI, HALF_PI = Math.PI / 2;
+  const sqrt = Math.sqrt, atan2 = Math.atan2, asin = Math.asin, pow = Math.pow, ceil = Math.ceil, max = Math.max, min = Math.min;
+
+  // ---- flatten the scene (A12) ----
+  const OX = new Float64Array(N), OY = new Float64Array(N), OZ = new Float64Array(N), R2 = new Float64Array(N);
+  const CR = new Float64Array(N), CG = new Float64Array(N), CB = new Float64Array(N), SE = new Float64Array(N), RI = new Float64Array(N);
+  const A0 = new Float64Array(N), A1 = new Float64Array(N), A2 = new Float64Array(N), A3 = new Float64Array(N), A4 = new Float64Array(N);
+  const KIND = new Int32Array(N), TEX = new Int32Array(N), FU = new Float64Array(N), FV = new Float64Array(N), CK = new Float64Array(N * 6);
+  scene.objects.forEach((o, i) => {
+    const m = o.mtl, s = m.sampler;
+    OX[i] = o.origin[0]; OY[i] = o.origin[1]; OZ[i] = o.origin[2]; R2[i] = o.r2;
+    CR[i] = m.color[0]; CG[i] = m.color[1]; CB[i] = m.color[2]; SE[i] = m.specular_exponent; RI[i] = m.refract_index;
+    A0[i] = m.albedo[0]; A1[i] = m.albedo[1]; A2[i] = m.albedo[2]; A3[i] = m.albedo[3]; A4[i] = m.albedo[4];
+    KIND[i] = s.kind; TEX[i] = s.kind === 1 ? s.texture : -1;
+    if (s.kind === 2) { FU[i] = s.freqU; FV[i] = s.freqV; for (let k = 0; k < 6; k++) CK[i * 6 + k] = s.colors[(k / 3) | 0][k % 3]; }
+  });
+  const LX = new Float64Array(NL), LY = new Float64Array(NL), LZ = new Float64Array(NL);
+  scene.lights.forEach((l, k) => { LX[k] = l[0]; LY[k] = l[1]; LZ[k] = l[2]; });
+  const TW = scene.textures.map((t) => t.width), TH = scene.textures.map((t) => t.height), TT = scene.textures.map((t) => t.texels);
+
+  const res = new Float64Array(3 * (SEGS + 2));   // result slot per recursion level
+  let nRays = 0, nShadow = 0, nTests = 0;
+  let hitInside = false;                          // side output of isect()
+
+  // main.js:420-439 (ext == null part): nearest root >= EPS, Infinity on miss, NaN passes through
+  function isect(i, px, py, pz, dx, dy, dz) {
+    nTests++;
+    const lx = OX[i] - px, ly = OY[i] - py, lz = OZ[i] - pz;
+    const tca = dx * lx + dy * ly + dz * lz;
+    const d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+    const r2 = R2[i];
+    if (d2 > r2) return INF;
+    const thc = sqrt(r2 - d2);
+    const t0 = tca - thc, t1 = tca + thc;
+    let t;
+    if (t0 < t1) {
+      if (t0 < EPS) { if (t1 < EPS) return INF; t = t1; } else t = t0;
+    } else {
+      if (t1 < EPS) { if (t0 < EPS) return INF; t = t0; } else t = t1;
+    }
+    hitInside = (t0 < EPS) || (t1 < EPS);         // main.js:445
+    return t;
+  }
+
+  // main.js:220-337; writes rgb to res[3*lvl..]
+  function trace(segs, lvl, px, py, pz, dx, dy, dz) {
+    const o = 3 * lvl;
+    if (segs === 0) { res[o] = 0; res[o + 1] = 0; res[o + 2] = 0; return; }
+    nRays++;
+    // A3: closest hit, strict <, first wins
+    let hi = -1, ht = INF, inside = false;
+    for (let i = 0; i < N; i++) {
+      const t = isect(i, px, py, pz, dx, dy, dz);
+      if (t < ht) { ht = t; hi = i; inside = hitInside; }
+    }
+    if (ht === INF) { res[o] = MISS[0]; res[o + 1] = MISS[1]; res[o + 2] = MISS[2]; return; }   // main.js:231
+    // A2 ext part (main.js:440-449), for the closest hit only (pure)
+    const hx = px + dx * ht, hy = py + dy * ht, hz = pz + dz * ht;
+    let nx = hx - OX[hi], ny = hy - OY[hi], nz = hz - OZ[hi];
+    const nl = sqrt(nx * nx + ny * ny + nz * nz);
+    if (nl !== 0) { const s = 1 / nl; nx = nx * s; ny = ny * s; nz = nz * s; }
+    let lx = nx, ly = ny, lz = nz;
+    if (inside) { lx = -nx; ly = -ny; lz = -nz; }
+    const a0 = A0[hi], a1 = A1[hi], a2 = A2[hi], a3 = A3[hi], a4 = A4[hi];
+
+    // A4: reflection direction (main.js:233-239)
+    let rx = 0, ry = 0, rz = 0, rlen = 0;
+    if (a3 > 0) {
+      const t = -(2 * (dx * nx + dy * ny + dz * nz));
+      rx = dx + nx * t; ry = dy + ny * t; rz = dz + nz * t;
+      rlen = sqrt(rx * rx + ry * ry + rz * rz);
+      if (rlen !== 0) { const s = 1 / rlen; rx = rx * s; ry = ry * s; rz = rz * s; }
+    }
+    // A5: refraction direction (main.js:241-266)
+    let fx = 0, fy = 0, fz = 0, flen = 0;
+    if (a4 > 0) {
+      let mx, my, mz, eta;
+      const d = dx * nx + dy * ny + dz * nz;
+      let cosi = -max(-1, min(1, d));
+      if (cosi < 0) { cosi = -cosi; mx = -nx; my = -ny; mz = -nz; eta = RI[hi]; }
+      else { mx = nx; my = ny; mz = nz; eta = 1 / RI[hi]; }
+      const k = 1 - eta * eta * (1 - cosi * cosi);
+      if (k > 0) {
+        const q = eta * cosi - sqrt(k);
+        fx = dx * eta + mx * q; fy = dy * eta + my * q; fz = dz * eta + mz * q;
+      } else {
+        const t = -(2 * (dx * mx + dy * my + dz * mz));
+        fx = dx + mx * t; fy = dy + my * t; fz = dz + mz * t;
+      }
+      flen = sqrt(fx * fx + fy * fy + fz * fz);
+      if (flen !== 0) { const s = 1 / flen; fx = fx * s; fy = fy * s; fz = fz * s; }
+    }
+    // A6: recursion, reflect before refract (main.js:268-278)
+    let reR = 0, reG = 0, reB = 0, rfR = 0, rfG = 0, rfB = 0;
+    if (rlen !== 0) {
+      trace(segs - 1, lvl + 1, hx, hy, hz, rx, ry, rz);
+      reR = res[o + 3] * a3; reG = res[o + 4] * a3; reB = res[o + 5] * a3;
+    }
+    if (flen !== 0) {
+      trace(segs - 1, lvl + 1, hx, hy, hz, fx, fy, fz);
+      rfR = res[o + 3] * a4; rfG = res[o + 4] * a4; rfB = res[o + 5] * a4;
+    }
+    // A7: lighting and shadows (main.js:280-318)
+    let diffuse = 0, specular = 0;
+    if (a1 > 0 || a2 > 0) {
+      let li = LI0;                                   // shared across lights (quirk q2)
+      for (let k = 0; k < NL; k++) {
+        let sx = LX[k] - hx, sy = LY[k] - hy, sz = LZ[k] - hz;
+        const lmag = sx * sx + sy * sy + sz * sz;
+        const llen = sqrt(lmag);
+        if (llen !== 0) { const s = 1 / llen; sx = sx * s; sy = sy * s; sz = sz * s; }
+        const sdot = sx * lx + sy * ly + sz * lz;
+        if (sdot <= 0) continue;
+        nShadow++;
+        for (let j = 0; j < N; j++) {
+          if (j === hi) continue;
+          const t = isect(j, hx, hy, hz, sx, sy, sz);
+          if (t < llen) {
+            if (A4[j] !== 0) li /= A4[j];
+            else { li = 0; break; }
+          }
+        }
+        if (li === 0) continue;
+        diffuse += li * sdot / lmag;
+        if (a2 > 0) {
+          const ldx = -sx, ldy = -sy, ldz = -sz;
+          const t = -(2 * (ldx * lx + ldy * ly + ldz * lz));
+          let qx = ldx + lx * t, qy = ldy + ly * t, qz = ldz + lz * t;
+          const ql = sqrt(qx * qx + qy * qy + qz * qz);
+          if (ql !== 0) { const s = 1 / ql; qx = qx * s; qy = qy * s; qz = qz * s; }
+          const spd = dx * -qx + dy * -qy + dz * -qz;
+          if (spd > 0) specular += pow(spd, SE[hi]);
+        }
+      }
+      diffuse = min(1, diffuse) * a1;
+      specular = min(1, specular) * a2;
+    }
+    // A8: sampler (main.js:320)
+    let cr, cg, cb;
+    const kind = KIND[hi];
+    if (kind === 0) { cr = CR[hi]; cg = CG[hi]; cb = CB[hi]; }
+    else if (kind === 1) {
+      const u = atan2(-nz, -nx) / PI / 2 + 0.5;       // main.js:446
+      const v = asin(-ny) / HALF_PI / 2 + 0.5;        // main.js:447
+      const ti = TEX[hi], W = TW[ti], texels = TT[ti];
+      const x = max(0, ceil(u * W) - 1);
+      const y = max(0, ceil(v * TH[ti]) - 1);
+      const i = (y * W + x) * 4;
+      cr = texels[i] / 255; cg = texels[i + 1] / 255; cb = texels[i + 2] / 255;
+    } else {
+      const u = atan2(-ny, -nx) / PI / 2 + 0.5;       // main.js:127
+      const v = asin(-nz) / HALF_PI / 2 + 0.5;        // main.js:128
+      const c = (((u * FU[hi]) & 1) ^ ((v * FV[hi]) & 1)) * 3 + hi * 6;
+      cr = CK[c]; cg = CK[c + 1]; cb = CK[c + 2];
+    }
+    // A9: combine (main.js:322-336)
+    res[o] = max(cr * a0, min(1, cr * diffuse + cr * specular + reR + rfR));
+    res[o + 1] = max(cg * a0, min(1, cg * diffuse + cg * specular + reG + rfG));
+    res[o + 2] = max(cb * a0, min(1, cb * diffuse + cb * specular + reB + rfB));
+  }
+
+  // ---- A1 + A10: per-pixel driver (main.js:102-105, 184-199) ----
+  const cam = scene.camera;
+  const cox = cam.origin[0], coy = cam.origin[1], coz = cam.origin[2];
+  const ax = cam.axisX, ay = cam.axisY, az = cam.axisZ;
+  const projA = scene.fovDeg * PI / 180, projW = w / 2, projH = h / 2, projD = projW / Math.tan(projA / 2);
+  const out = new Uint8ClampedArray(nRows * w * 4);
+  let i = 0;
+  for (let ry = 0; ry < nRows; ry++) {
+    const y = rowList[ry];
+    for (let x = 0; x < w; x++) {
+      const d0 = x - projW + 0.5, d1 = projH - y - 0.5, d2 = projD;
+      // dist is indexed by COMPONENT, not by axis (quirk q1)
+      const tx = cox + ax[0] * d0 + ay[0] * d0 + az[0] * d0;
+      const ty = coy + ax[1] * d1 + ay[1] * d1 + az[1] * d1;
+      const tz = coz + ax[2] * d2 + ay[2] * d2 + az[2] * d2;
+      let rx = tx - cox, ry = ty - coy, rz = tz - coz;
+      const l = sqrt(rx * rx + ry * ry + rz * rz);
+      if (l !== 0) { const s = 1 / l; rx = rx * s; ry = ry * s; rz = rz * s; }
+      trace(SEGS, 0, cox, coy, coz, rx, ry, rz);
+      out[i++] = 255 * res[0]; out[i++] = 255 * res[1]; out[i++] = 255 * res[2]; out[i++] = 255;
+    }
+  }
+  return {rgba: new Uint8Array(out.buffer), pixels: nRows * w, rays: nRays, shadowRays: nShadow, sphereTests: nTests};
+}
+
+module.exports = {render};
