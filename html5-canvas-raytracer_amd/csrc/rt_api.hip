@@ -1,0 +1,477 @@
+// rt_api.hip — the C ABI of include/rt_hip.h: scene validation/upload, launches, pinned
+// framebuffers, and the single-process multi-GPU frame (interleaved row tiles + one RCCL gather).
+//
+// Host-side counterpart of the reference's driver code: main() sets up what a frame needs
+// (main.js:77-105), redraw()/spanish() walks the rows (:180-201).  Here a frame is one kernel
+// launch per GPU.  There is no CPU rendering path in this library: without a GPU every render
+// entry point fails with RT_ERR_DEVICE.
+
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include "rt_device.h"
+
+extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, unsigned, hipStream_t);
+extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, unsigned, hipStream_t);
+
+// ------------------------------------------------------------------------------------ state
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+struct device_state {
+  int hip_id = -1;
+  hipStream_t stream = nullptr;          // created on first use
+  unsigned long long *d_counters = nullptr;
+  void *d_frame = nullptr;               // rt_render scratch: this device's tiles (or the whole frame)
+  size_t frame_bytes = 0;
+  void *d_gather = nullptr;              // device 0 only: gather target
+  size_t gather_bytes = 0;
+};
+
+struct lib_state {
+  bool inited = false;
+  std::vector<device_state> dev;
+  std::mutex mu;
+  // RCCL, resolved lazily with dlopen so that single-GPU users never load it
+  void *rccl = nullptr;
+  void *comms[16] = {nullptr};
+  bool comms_ready = false;
+} G;
+
+int ensure_device(int d) {
+  if (!G.inited) return fail(RT_ERR_STATE, "rt_init has not been called");
+  if (d < 0 || d >= (int)G.dev.size()) return fail(RT_ERR_INVALID, "device %d out of range (0..%d)", d, (int)G.dev.size() - 1);
+  device_state &s = G.dev[d];
+  HIP_TRY(hipSetDevice(s.hip_id));
+  if (!s.stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&s.d_counters, 3 * sizeof(unsigned long long)));
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+struct rt_scene_dev {
+  int device;
+  void *d_blob;                  // the uploaded scene blob
+  rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
+  rt_scene_header hd;            // host copy
+  bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
+  unsigned lds_bytes;
+  double lights[RT_MAX_LIGHTS][3];   // host copy: lights travel in the kernarg segment
+};
+
+// ------------------------------------------------------------------------------------ lifetime
+extern "C" uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" const char *rt_last_error(void) { return g_err; }
+
+extern "C" int rt_init(int max_devices) {
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (G.inited) return RT_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RT_ERR_DEVICE, "no HIP device visible (%s); this library has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+  if (max_devices > 0 && n > max_devices) n = max_devices;
+  if (n > 16) n = 16;
+  G.dev.resize(n);
+  for (int i = 0; i < n; i++) G.dev[i].hip_id = i;
+  G.inited = true;
+  return RT_OK;
+}
+
+extern "C" int rt_device_count(void) {
+  if (!G.inited) return fail(RT_ERR_STATE, "rt_init has not been called");
+  return (int)G.dev.size();
+}
+
+// ------------------------------------------------------------------------------------ validation (host logic only)
+extern "C" int rt_scene_validate(const void *blob, size_t bytes) {
+  if (!blob || bytes < sizeof(rt_scene_header)) return fail(RT_ERR_INVALID, "scene blob shorter than its header");
+  if (((uintptr_t)blob & 7u) != 0) return fail(RT_ERR_INVALID, "scene blob must be 8-byte aligned");
+  const rt_scene_header *hd = (const rt_scene_header *)blob;
+  if (hd->magic != RT_SCENE_MAGIC) return fail(RT_ERR_INVALID, "bad scene magic 0x%08x", hd->magic);
+  if (hd->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID, "scene ABI version %u, library speaks %u", hd->abi_version, RT_ABI_VERSION);
+  if (hd->total_bytes != bytes) return fail(RT_ERR_INVALID, "total_bytes %llu != blob size %zu", (unsigned long long)hd->total_bytes, bytes);
+  if (hd->n_objects < 1 || hd->n_objects > RT_MAX_OBJECTS) return fail(RT_ERR_INVALID, "n_objects %u not in 1..%u", hd->n_objects, RT_MAX_OBJECTS);
+  if (hd->n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_INVALID, "n_lights %u > %u", hd->n_lights, RT_MAX_LIGHTS);
+  if (hd->n_textures > RT_MAX_TEXTURES) return fail(RT_ERR_INVALID, "n_textures %u > %u", hd->n_textures, RT_MAX_TEXTURES);
+  if (hd->segs > RT_MAX_SEGS) return fail(RT_ERR_INVALID, "segs %u > %u", hd->segs, RT_MAX_SEGS);
+  if (hd->supersample != 1 && hd->supersample != 2) return fail(RT_ERR_INVALID, "supersample must be 1 or 2");
+  if (!(hd->fov_deg > 0.0 && hd->fov_deg < 180.0)) return fail(RT_ERR_INVALID, "fov_deg must be in (0,180)");
+  auto in_range = [&](uint64_t off, uint64_t len) { return (off & 7u) == 0 && off >= sizeof(rt_scene_header) && off <= bytes && len <= bytes - off; };
+  if (!in_range(hd->objects_offset, (uint64_t)hd->n_objects * sizeof(rt_sphere))) return fail(RT_ERR_INVALID, "object table out of bounds");
+  if (!in_range(hd->lights_offset, (uint64_t)hd->n_lights * 24u)) return fail(RT_ERR_INVALID, "light table out of bounds");
+  if (!in_range(hd->textures_offset, (uint64_t)hd->n_textures * sizeof(rt_texture_desc))) return fail(RT_ERR_INVALID, "texture table out of bounds");
+  const uint8_t *base = (const uint8_t *)blob;
+  const rt_texture_desc *td = (const rt_texture_desc *)(base + hd->textures_offset);
+  for (uint32_t t = 0; t < hd->n_textures; t++) {
+    if (td[t].width == 0 || td[t].height == 0 || td[t].width > 16384 || td[t].height > 16384) return fail(RT_ERR_INVALID, "texture %u: bad size", t);
+    if ((td[t].texels_offset & 3u) != 0 || td[t].texels_offset > bytes || (uint64_t)td[t].width * td[t].height * 4u > bytes - td[t].texels_offset)
+      return fail(RT_ERR_INVALID, "texture %u: texels out of bounds", t);
+  }
+  const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
+  for (uint32_t i = 0; i < hd->n_objects; i++) {
+    const int k = ob[i].sampler_kind;
+    if (k != RT_SAMPLER_COLOR && k != RT_SAMPLER_TEXTURE && k != RT_SAMPLER_CHECKER)
+      return fail(RT_ERR_UNSUPPORTED, "object %u: sampler kind %d is not supported (the Math.random stars sampler of main.js:135-139 cannot be reproduced)", i, k);
+    if (k == RT_SAMPLER_TEXTURE && (ob[i].texture < 0 || (uint32_t)ob[i].texture >= hd->n_textures))
+      return fail(RT_ERR_INVALID, "object %u: texture index %d out of range", i, ob[i].texture);
+  }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------ upload
+extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
+  if (!out) return fail(RT_ERR_INVALID, "out handle is NULL");
+  *out = nullptr;
+  int rc = rt_scene_validate(blob, bytes);
+  if (rc) return rc;
+  if ((rc = ensure_device(device))) return rc;
+  const rt_scene_header *hd = (const rt_scene_header *)blob;
+  rt_scene_dev *s = new rt_scene_dev();
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr;
+  const uint8_t *base = (const uint8_t *)blob;
+  const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
+  s->refract = false;
+  for (uint32_t i = 0; i < hd->n_objects; i++) if (ob[i].albedo[4] > 0.0) s->refract = true;
+  s->lds_bytes = hd->n_objects * (unsigned)sizeof(rt_sphere) + RT_MAX_TEXTURES * (unsigned)sizeof(rt_texture_desc);
+  memset(s->lights, 0, sizeof s->lights);
+  if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
+  rt_texture_desc descs[RT_MAX_TEXTURES];
+  memset(descs, 0, sizeof descs);
+  if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
+  hipError_t e = hipMalloc(&s->d_blob, bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
+  if (e == hipSuccess) e = hipMemcpy(s->d_blob, blob, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->d_texdesc, descs, sizeof descs, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (s->d_blob) (void)hipFree(s->d_blob);
+    if (s->d_texdesc) (void)hipFree(s->d_texdesc);
+    delete s;
+    return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return RT_OK;
+}
+
+extern "C" void rt_scene_free(rt_scene_dev *s) {
+  if (!s) return;
+  if (G.inited && s->device < (int)G.dev.size()) (void)hipSetDevice(G.dev[s->device].hip_id);
+  (void)hipFree(s->d_blob);
+  (void)hipFree(s->d_texdesc);
+  delete s;
+}
+
+// ------------------------------------------------------------------------------------ launch
+extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, void *d_out, void *hip_stream,
+                                      uint32_t flags, rt_stats *stats) {
+  if (!s || !tiles || !d_out) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
+  if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "frame size %ux%u not in 1..65536", w, h);
+  if (tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0) return fail(RT_ERR_INVALID, "empty tile set");
+  if ((uint64_t)tiles->n_tiles * tiles->tile_rows > (1ull << 24)) return fail(RT_ERR_INVALID, "too many rows in one call");
+  int rc = ensure_device(s->device);
+  if (rc) return rc;
+  device_state &D = G.dev[s->device];
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : D.stream;
+  const auto t_begin = std::chrono::steady_clock::now();
+
+  const rt_scene_header &hd = s->hd;
+  const bool ss2 = hd.supersample == 2;
+  rt_launch L;
+  memset(&L, 0, sizeof L);
+  const uint8_t *db = (const uint8_t *)s->d_blob;
+  L.objects = (const rt_sphere *)(db + hd.objects_offset);
+  L.textures = s->d_texdesc;
+  L.texel_base = db;
+  L.out = (uint32_t *)d_out;
+  L.counters = D.d_counters;
+  memcpy(L.cam_origin, hd.cam_origin, 12 * sizeof(double));   // origin, axisX, axisY, axisZ are contiguous
+  // projection constants (main.js:102-105) of the sample grid, in binary64 on the host
+  const double sw = ss2 ? 2.0 * w : (double)w, sh = ss2 ? 2.0 * h : (double)h;
+  const double projA = hd.fov_deg * M_PI / 180.0;
+  L.proj_w = sw / 2.0; L.proj_h = sh / 2.0; L.proj_d = L.proj_w / tan(projA / 2.0);
+  L.epsilon = hd.epsilon; L.light_intensity = hd.light_intensity;
+  memcpy(L.miss_color, hd.miss_color, sizeof L.miss_color);
+  L.n_objects = hd.n_objects; L.n_lights = hd.n_lights; L.segs = hd.segs;
+  L.w = w; L.h = h;
+  L.tile_rows = tiles->tile_rows; L.tile_first = tiles->tile_first; L.tile_stride = tiles->tile_stride; L.n_tiles = tiles->n_tiles;
+  L.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
+  memcpy(L.lights, s->lights, sizeof L.lights);
+
+  const uint32_t local_rows = tiles->n_tiles * tiles->tile_rows;
+  const uint32_t rows_per_wg = ss2 ? 2u : RT_TILE_H;
+  const uint64_t blocks = (uint64_t)L.tiles_x * ((local_rows + rows_per_wg - 1) / rows_per_wg);
+  if (blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "grid too large");
+  const bool count = (flags & RT_FLAG_COUNT) != 0;
+  if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+  const int err = ((flags & RT_FLAG_STRICT_FP) ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, (unsigned)blocks, s->lds_bytes, stream);
+  if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
+  if (stats) {
+    HIP_TRY(hipEventRecord(ev1, stream));
+    HIP_TRY(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    memset(stats, 0, sizeof *stats);
+    stats->kernel_ms = ms;
+    uint64_t px = 0;
+    for (uint32_t i = 0; i < tiles->n_tiles; i++) {
+      const uint64_t r0 = (uint64_t)(tiles->tile_first + (uint64_t)i * tiles->tile_stride) * tiles->tile_rows;
+      if (r0 < h) px += ((r0 + tiles->tile_rows <= h) ? tiles->tile_rows : (h - r0)) * (uint64_t)w;
+    }
+    stats->pixels = px;
+    if (count) {
+      unsigned long long c[3];
+      HIP_TRY(hipMemcpy(c, D.d_counters, sizeof c, hipMemcpyDeviceToHost));
+      stats->rays = c[0]; stats->shadow_rays = c[1]; stats->sphere_tests = c[2];
+    }
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------ memory helpers
+extern "C" void *rt_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { fail(RT_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+extern "C" void rt_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" void *rt_alloc_device(int device, size_t bytes) {
+  if (ensure_device(device)) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { fail(RT_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+extern "C" void rt_free_device(int device, void *p) {
+  if (!p || ensure_device(device)) return;
+  (void)hipFree(p);
+}
+extern "C" int rt_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(G.dev[device].stream));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------ de-interleave
+// src: for rank g, its tiles (g, g+R, g+2R, ...) stored contiguously, ranks `rank_stride` bytes apart.
+// dst: the frame in row order.  One work-item moves 16 bytes; rows are w*4 bytes (w % 4 == 0 fast path).
+__global__ void __launch_bounds__(256) rt_deinterleave_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t w, uint32_t h,
+                                                              uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_words) {
+  const uint64_t total = (uint64_t)w * h;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t row = (uint32_t)(i / w), x = (uint32_t)(i - (uint64_t)row * w);
+    const uint32_t tile = row / tile_rows, r = row - tile * tile_rows;
+    const uint32_t rank = tile % n_ranks, local_tile = tile / n_ranks;
+    dst[i] = src[rank * rank_stride_words + ((uint64_t)local_tile * tile_rows + r) * w + x];
+  }
+}
+
+extern "C" int rt_deinterleave_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h, uint32_t tile_rows, uint32_t n_ranks,
+                                      uint64_t rank_stride_bytes, void *hip_stream) {
+  if (!d_src || !d_dst || !w || !h || !tile_rows || !n_ranks || (rank_stride_bytes & 3u)) return fail(RT_ERR_INVALID, "bad de-interleave arguments");
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[device].stream;
+  const uint64_t total = (uint64_t)w * h;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 256u * 16u) blocks = 256u * 16u;
+  hipLaunchKernelGGL(rt_deinterleave_kernel, dim3(blocks), dim3(256), 0, stream, (const uint32_t *)d_src, (uint32_t *)d_dst, w, h, tile_rows, n_ranks,
+                     rank_stride_bytes / 4u);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------ RCCL (lazy)
+namespace {
+typedef int (*nccl_comm_init_all_t)(void **comms, int ndev, const int *devlist);
+typedef int (*nccl_gather_t)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t stream);
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_comm_destroy_t)(void *comm);
+typedef const char *(*nccl_errstr_t)(int);
+struct { nccl_comm_init_all_t init_all; nccl_gather_t gather; nccl_group_t group_start, group_end; nccl_comm_destroy_t destroy; nccl_errstr_t errstr; } NCCL;
+const int NCCL_UINT8 = 1;   // ncclUint8 (rccl.h ncclDataType_t)
+
+int ensure_rccl(int ndev) {
+  if (G.comms_ready) return RT_OK;
+  if (!G.rccl) {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) if ((G.rccl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!G.rccl) return fail(RT_ERR_DEVICE, "cannot load RCCL: %s", dlerror());
+    NCCL.init_all = (nccl_comm_init_all_t)dlsym(G.rccl, "ncclCommInitAll");
+    NCCL.gather = (nccl_gather_t)dlsym(G.rccl, "ncclGather");
+    NCCL.group_start = (nccl_group_t)dlsym(G.rccl, "ncclGroupStart");
+    NCCL.group_end = (nccl_group_t)dlsym(G.rccl, "ncclGroupEnd");
+    NCCL.destroy = (nccl_comm_destroy_t)dlsym(G.rccl, "ncclCommDestroy");
+    NCCL.errstr = (nccl_errstr_t)dlsym(G.rccl, "ncclGetErrorString");
+    if (!NCCL.init_all || !NCCL.gather || !NCCL.group_start || !NCCL.group_end || !NCCL.destroy || !NCCL.errstr)
+      return fail(RT_ERR_DEVICE, "RCCL is missing ncclCommInitAll/ncclGather/ncclGroup*");
+  }
+  int ids[16];
+  for (int i = 0; i < ndev; i++) ids[i] = G.dev[i].hip_id;
+  const int r = NCCL.init_all(G.comms, ndev, ids);
+  if (r != 0) return fail(RT_ERR_DEVICE, "ncclCommInitAll: %s", NCCL.errstr(r));
+  G.comms_ready = true;
+  return RT_OK;
+}
+
+int ensure_frame(device_state &D, size_t bytes) {
+  if (D.frame_bytes >= bytes) return RT_OK;
+  if (D.d_frame) (void)hipFree(D.d_frame);
+  D.d_frame = nullptr; D.frame_bytes = 0;
+  HIP_TRY(hipMalloc(&D.d_frame, bytes));
+  D.frame_bytes = bytes;
+  return RT_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------ render(width,height,scene)
+extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats) {
+  if (!out_rgba) return fail(RT_ERR_INVALID, "out_rgba is NULL");
+  if (!G.inited) return fail(RT_ERR_STATE, "rt_init has not been called");
+  std::lock_guard<std::mutex> lk(G.mu);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int ndev = (int)G.dev.size();
+  const size_t frame_bytes = (size_t)w * h * 4u;
+  int rc;
+  rt_stats agg;
+  memset(&agg, 0, sizeof agg);
+
+  if (ndev == 1 || h < (uint32_t)ndev * RT_TILE_H) {
+    // ---- one GPU: one launch, one copy-out ----
+    rt_scene_dev *s = nullptr;
+    if ((rc = rt_scene_upload(0, blob, bytes, &s))) return rc;
+    device_state &D = G.dev[0];
+    rt_tiles whole = {h, 0, 1, 1};
+    rt_stats st;
+    rc = ensure_frame(D, frame_bytes);
+    if (!rc) rc = rt_render_tiles_device(s, w, h, &whole, D.d_frame, nullptr, flags, &st);
+    if (!rc) {
+      hipError_t e = hipMemcpyAsync(out_rgba, D.d_frame, frame_bytes, hipMemcpyDeviceToHost, D.stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+      if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+    }
+    rt_scene_free(s);
+    if (rc) return rc;
+    agg = st;
+  } else {
+    // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
+    //      GPU stores its tiles contiguously, ONE RCCL gather to GPU 0 over xGMI, one de-interleave pass ----
+    if ((rc = ensure_rccl(ndev))) return rc;
+    const uint32_t tile_rows = (h >= (uint32_t)ndev * 64u) ? 16u : RT_TILE_H;
+    const uint32_t n_tiles_total = (h + tile_rows - 1) / tile_rows;
+    const uint32_t tiles_per_rank = (n_tiles_total + ndev - 1) / ndev;
+    const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * 4u;
+    std::vector<rt_scene_dev *> scenes(ndev, nullptr);
+    rc = RT_OK;
+    for (int g = 0; g < ndev && !rc; g++) {
+      rc = rt_scene_upload(g, blob, bytes, &scenes[g]);
+      if (!rc) rc = ensure_frame(G.dev[g], band_bytes);
+    }
+    if (!rc) {
+      device_state &R = G.dev[0];
+      HIP_TRY(hipSetDevice(R.hip_id));
+      if (R.gather_bytes < band_bytes * ndev + frame_bytes) {
+        if (R.d_gather) (void)hipFree(R.d_gather);
+        R.d_gather = nullptr; R.gather_bytes = 0;
+        HIP_TRY(hipMalloc(&R.d_gather, band_bytes * ndev + frame_bytes));
+        R.gather_bytes = band_bytes * ndev + frame_bytes;
+      }
+    }
+    std::vector<hipEvent_t> ev0(ndev, nullptr), ev1(ndev, nullptr);
+    for (int g = 0; g < ndev && !rc; g++) {
+      rt_tiles t = {tile_rows, (uint32_t)g, (uint32_t)ndev, tiles_per_rank};
+      if ((rc = ensure_device(g))) break;
+      (void)hipEventCreate(&ev0[g]); (void)hipEventCreate(&ev1[g]);
+      (void)hipEventRecord(ev0[g], G.dev[g].stream);
+      rc = rt_render_tiles_device(scenes[g], w, h, &t, G.dev[g].d_frame, nullptr, flags & ~RT_FLAG_COUNT, nullptr);
+      (void)hipEventRecord(ev1[g], G.dev[g].stream);
+    }
+    if (!rc) {
+      NCCL.group_start();
+      for (int g = 0; g < ndev; g++) {
+        (void)hipSetDevice(G.dev[g].hip_id);
+        const int r = NCCL.gather(G.dev[g].d_frame, g == 0 ? G.dev[0].d_gather : nullptr, band_bytes, NCCL_UINT8, 0, G.comms[g], G.dev[g].stream);
+        if (r != 0 && !rc) rc = fail(RT_ERR_DEVICE, "ncclGather: %s", NCCL.errstr(r));
+      }
+      NCCL.group_end();
+    }
+    if (!rc) {
+      device_state &R = G.dev[0];
+      uint8_t *d_final = (uint8_t *)R.d_gather + band_bytes * ndev;
+      rc = rt_deinterleave_device(0, R.d_gather, d_final, w, h, tile_rows, (uint32_t)ndev, band_bytes, nullptr);
+      if (!rc) {
+        (void)hipSetDevice(R.hip_id);
+        hipError_t e = hipMemcpyAsync(out_rgba, d_final, frame_bytes, hipMemcpyDeviceToHost, R.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
+        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+      }
+    }
+    for (int g = 0; g < ndev; g++) {
+      (void)hipSetDevice(G.dev[g].hip_id);
+      if (G.dev[g].stream) (void)hipStreamSynchronize(G.dev[g].stream);
+      if (ev0[g] && ev1[g]) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev0[g], ev1[g]) == hipSuccess && ms > agg.kernel_ms) agg.kernel_ms = ms;   // slowest GPU
+      }
+      if (ev0[g]) (void)hipEventDestroy(ev0[g]);
+      if (ev1[g]) (void)hipEventDestroy(ev1[g]);
+      rt_scene_free(scenes[g]);
+    }
+    if (rc) return rc;
+    agg.pixels = (uint64_t)w * h;
+  }
+  agg.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (stats) *stats = agg;
+  return RT_OK;
+}
+
+extern "C" void rt_shutdown(void) {
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (!G.inited) return;
+  if (G.comms_ready) { for (size_t g = 0; g < G.dev.size(); g++) if (G.comms[g]) NCCL.destroy(G.comms[g]); G.comms_ready = false; }
+  for (device_state &D : G.dev) {
+    if (!D.stream) continue;
+    (void)hipSetDevice(D.hip_id);
+    (void)hipStreamSynchronize(D.stream);
+    if (D.d_frame) (void)hipFree(D.d_frame);
+    if (D.d_gather) (void)hipFree(D.d_gather);
+    if (D.d_counters) (void)hipFree(D.d_counters);
+    (void)hipStreamDestroy(D.stream);
+    D = device_state();
+  }
+  G.dev.clear();
+  G.inited = false;
+}

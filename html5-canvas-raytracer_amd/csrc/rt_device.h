@@ -1,0 +1,36 @@
+// Kernel-side view of a resident scene and of one launch.  Shared by rt_api.cpp (host) and
+// rt_kernel.hip (device).  Not part of the ABI (include/rt_hip.h is).
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+#include "../../include/rt_hip.h"
+
+// Workgroup geometry: 256 work-items = 4 waves of 64.  A wave owns an 8x8 pixel block (compact,
+// so its 64 rays stay coherent); the 4 waves sit side by side, so a workgroup owns a 32x8 tile
+// whose every row is one whole 128-byte line of the RGBA8 framebuffer.
+#define RT_WG_THREADS 256
+#define RT_TILE_W 32
+#define RT_TILE_H 8
+
+// Everything one launch needs, passed by value in the kernarg segment (scalar-loaded into
+// SGPRs: all of it is wave-uniform).
+struct rt_launch {
+  // resident scene (HBM)
+  const rt_sphere *objects;          // n_objects records of 192 B; geometry = first 32 B of each
+  const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`
+  const uint8_t *texel_base;
+  uint32_t *out;                     // RGBA8 packed little-endian (R in the low byte)
+  unsigned long long *counters;      // rays, shadow rays, sphere tests (COUNT variant only)
+  // camera + projection (main.js:85-105), projection constants computed on the host in binary64
+  double cam_origin[3], cam_axis_x[3], cam_axis_y[3], cam_axis_z[3];
+  double proj_w, proj_h, proj_d;     // of the SAMPLE grid (2w x 2h when supersampling)
+  double epsilon, light_intensity, miss_color[3];
+  double lights[RT_MAX_LIGHTS][3];
+  uint32_t n_objects, n_lights, segs;
+  uint32_t w, h;                     // output frame size in pixels
+  uint32_t tile_rows, tile_first, tile_stride, n_tiles;   // rt_tiles
+  uint32_t tiles_x;                  // workgroup tiles per row of the frame
+};
+
+#endif

@@ -1,0 +1,363 @@
+// rt_kernel.hip — the per-pixel ray-sphere trace/shade loop as ONE hand-written gfx950 kernel.
+//
+// What it computes, per output pixel (reference lines in /root/reference/main.js):
+//   A1  primary ray                     :102-105, :186-193   (dist indexed by component, quirk q1)
+//   A2  ray-sphere intersection         :420-451
+//   A3  closest hit, strict <           :223-231
+//   A4  reflection / A5 refraction      :233-266
+//   A6  bounded recursion               :221, :268-278       (explicit per-lane stack, post-order fold)
+//   A7  lights, shadows, Phong          :280-318              (light_intensity shared across lights, q2)
+//   A8  samplers (colour/texture/checker) :404, :343-351, :126-133
+//   A9  combine + non-linear clamp      :320-336
+//   A10 RGBA8 store                     :195-198              (Uint8ClampedArray: clamp, round-half-even)
+//
+// MI355X mapping (no MFMA: there is no dense contraction anywhere in this path; all arithmetic is
+// binary64 VALU, which is what JS numbers are):
+//   * one work-item per pixel (per SAMPLE when supersampling); a wave owns a compact 8x8 block so its
+//     64 rays take the same branches; 4 waves side by side make a 32x8 workgroup tile = whole
+//     128-byte framebuffer lines, each line written by exactly one workgroup (no cross-XCD sharing);
+//   * everything wave-uniform — camera, lights, loop bounds (kernarg) and the sphere geometry walked
+//     by the uniform object loops — is read with SCALAR loads into SGPRs, so the intersection loops
+//     issue no vector memory and no LDS traffic at all;
+//   * the per-hit, per-lane data (material + sampler parameters of the sphere that lane hit, texture
+//     descriptors) is staged once per workgroup into LDS and indexed by the lane's hit id;
+//   * texels are plain global loads (gfx950 has no image/texture path); the two 128 KB textures
+//     stay L2-resident;
+//   * divergent phases are guarded by exec-mask branches the compiler lowers to s_cbranch_execz
+//     (whole-wave skip of the sqrt path when no lane's ray meets the sphere, of lighting when every
+//     lane hit an emissive-only surface, of the shadow scan when every lane is already occluded),
+//     and the bounce loop runs while __ballot says any lane still has a ray in flight.
+//
+// The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (default product
+// kernel) and RT_STRICT=1 with -ffp-contract=off (operation-for-operation with the JS expression
+// trees; RT_FLAG_STRICT_FP).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+#ifndef RT_STRICT
+#define RT_STRICT 0
+#endif
+#if RT_STRICT
+#define RT_LAUNCH_NAME rt_launch_trace_strict
+#else
+#define RT_LAUNCH_NAME rt_launch_trace_fast
+#endif
+
+#define RT_INF __builtin_inf()
+
+namespace {
+
+struct v3 { double x, y, z; };
+__device__ __forceinline__ v3 mk(double x, double y, double z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+// main.js:49-51 — (a0*b0 + a1*b1) + a2*b2
+__device__ __forceinline__ double dot(const v3 a, const v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// main.js:62-66 — multiply by 1/len; the zero vector is returned unchanged
+__device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
+  const double l = sqrt(dot(v, v));
+  *len_out = l;
+  if (l != 0.0) { const double s = 1.0 / l; return mk(v.x * s, v.y * s, v.z * s); }
+  return v;
+}
+// main.js:40-43 — v + n * (-(2 * v.n))
+__device__ __forceinline__ v3 reflect(const v3 v, const v3 n) {
+  const double t = -(2.0 * dot(v, n));
+  return mk(v.x + n.x * t, v.y + n.y * t, v.z + n.z * t);
+}
+// Math.min(1, x) / Math.max(a, x) as used at main.js:316-317, :333-335 (NaN in x propagates)
+__device__ __forceinline__ double min1(double x) { return (x > 1.0) ? 1.0 : x; }
+__device__ __forceinline__ double maxa(double a, double x) { return (x < a) ? a : x; }
+
+// ECMAScript ToInt32(x) & 1   (main.js:129-130)
+__device__ __forceinline__ int to_int32_bit0(double x) {
+  if (!(fabs(x) < RT_INF)) return 0;                 // NaN, +-Infinity -> 0
+  double t = trunc(x);
+  if (fabs(t) >= 4294967296.0) t = t - floor(t / 4294967296.0) * 4294967296.0;
+  return (int)((long long)t & 1);
+}
+
+// Uint8ClampedArray store of 255*c (main.js:195-197): NaN -> 0, clamp, round half to even
+__device__ __forceinline__ uint32_t to_byte(double c) {
+  const double v = 255.0 * c;
+  if (!(v > 0.0)) return 0u;
+  if (v >= 255.0) return 255u;
+  return (uint32_t)rint(v);
+}
+
+// main.js:420-439.  Returns the nearest root >= eps (Infinity on a miss; NaN passes through and
+// loses every later comparison, exactly as in the reference); *inside = (t0 < eps), which for a
+// returned root equals the reference's (t0 < 0.001) || (t1 < 0.001) because t0 <= t1.
+__device__ __forceinline__ double isect(const double ox, const double oy, const double oz, const double r2,
+                                        const v3 p, const v3 d, const double eps, bool *inside) {
+  const v3 L = mk(ox - p.x, oy - p.y, oz - p.z);
+  const double tca = dot(d, L);
+  const double d2 = dot(L, L) - tca * tca;
+  double t = RT_INF;
+  *inside = false;
+  if (!(d2 > r2)) {                                  // wave-wide skip of the sqrt path on a full miss
+    const double thc = sqrt(r2 - d2);
+    const double t0 = tca - thc, t1 = tca + thc;
+    // thc >= 0 (or NaN), so t0 <= t1: both arms of the reference's if (t0 < t1) select the same value
+    t = (t0 < eps) ? ((t1 < eps) ? RT_INF : t1) : t0;
+    *inside = (t0 < eps);
+  }
+  return t;
+}
+
+// A frame of the explicit recursion stack: everything intersectWorld still needs after its
+// recursive calls return (main.js:320-336) — the lighting and sampler terms do not depend on the
+// children, so they are evaluated before descending.
+template <bool REFRACT> struct frame;
+template <> struct frame<false> { double amb[3], ds[3], a3; };
+template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3]; int has_f, phase; };
+
+template <bool REFRACT, bool COUNT>
+__device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
+                                            v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
+  const rt_sphere *__restrict__ objs = L.objects;
+  const uint32_t N = L.n_objects, NL = L.n_lights;
+  const double eps = L.epsilon;
+  frame<REFRACT> stack[RT_MAX_SEGS];
+  int level = 0;
+  uint32_t segs_left = L.segs;
+  double ret[3] = {0.0, 0.0, 0.0};
+
+  if (segs_left != 0) {
+    for (;;) {
+      // ---------------- evaluate one intersectWorld node (segs_left > 0 here) ----------------
+      if (COUNT) cnt[0]++;
+      // A3: closest hit.  Uniform trip count, sphere geometry via scalar loads.
+      double ht = RT_INF; int hi = -1; bool inside = false;
+      for (uint32_t i = 0; i < N; i++) {
+        bool in;
+        const double t = isect(objs[i].origin[0], objs[i].origin[1], objs[i].origin[2], objs[i].r2, p, d, eps, &in);
+        if (t < ht) { ht = t; hi = (int)i; inside = in; }
+      }
+      if (COUNT) cnt[2] += N;
+      bool descend = false;
+      if (hi < 0) {                                   // main.js:231
+        ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
+      } else {
+        const rt_sphere &m = mtl[hi];                 // LDS, per-lane index
+        // A2 ext part for the closest hit only (main.js:440-447; pure, so deferring it is exact)
+        const v3 h = mk(p.x + d.x * ht, p.y + d.y * ht, p.z + d.z * ht);
+        double nlen;
+        const v3 n = unit(mk(h.x - m.origin[0], h.y - m.origin[1], h.z - m.origin[2]), &nlen);
+        const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
+        const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
+        const double a4 = REFRACT ? m.albedo[4] : 0.0;
+
+        // A4 reflection direction
+        v3 r = mk(0, 0, 0); double rlen = 0.0;
+        if (a3 > 0.0) r = unit(reflect(d, n), &rlen);
+        // A5 refraction direction
+        v3 f = mk(0, 0, 0); double flen = 0.0;
+        if (REFRACT && a4 > 0.0) {
+          const double dn = dot(d, n);
+          double cosi = -((dn < -1.0) ? -1.0 : min1(dn));              // -Math.max(-1, Math.min(1, dot))
+          v3 nn = n; double eta;
+          if (cosi < 0.0) { cosi = -cosi; nn = mk(-n.x, -n.y, -n.z); eta = m.refract_index; }
+          else eta = 1.0 / m.refract_index;
+          const double k = 1.0 - eta * eta * (1.0 - cosi * cosi);
+          if (k > 0.0) {
+            const double q = eta * cosi - sqrt(k);
+            f = mk(d.x * eta + nn.x * q, d.y * eta + nn.y * q, d.z * eta + nn.z * q);
+          } else f = reflect(d, nn);                                   // total internal reflection
+          f = unit(f, &flen);
+        }
+
+        // A7 lighting and shadows
+        double diffuse = 0.0, specular = 0.0;
+        if (a1 > 0.0 || a2 > 0.0) {
+          double li = L.light_intensity;                               // shared across lights (q2)
+          for (uint32_t k = 0; k < NL; k++) {
+            double llen;
+            const v3 sraw = mk(L.lights[k][0] - h.x, L.lights[k][1] - h.y, L.lights[k][2] - h.z);
+            const double lmag = dot(sraw, sraw);
+            const v3 sv = unit(sraw, &llen);
+            const double sdot = dot(sv, l);
+            if (sdot <= 0.0) continue;                                 // surface faces away
+            if (COUNT) cnt[1]++;
+            uint32_t tests = 0;
+            for (uint32_t j = 0; j < N; j++) {
+              if ((int)j == hi) continue;                              // main.js:294 (q3)
+              bool in;
+              const double t = isect(objs[j].origin[0], objs[j].origin[1], objs[j].origin[2], objs[j].r2, h, sv, eps, &in);
+              tests++;
+              if (t < llen) {
+                const double oa4 = objs[j].albedo[4];
+                if (oa4 != 0.0) li /= oa4;                             // transparent occluder brightens (q2)
+                else { li = 0.0; break; }
+              }
+            }
+            if (COUNT) cnt[2] += tests;
+            if (li == 0.0) continue;
+            diffuse += li * sdot / lmag;
+            if (a2 > 0.0) {
+              double ql;
+              const v3 q = unit(reflect(mk(-sv.x, -sv.y, -sv.z), l), &ql);
+              const double spd = d.x * -q.x + d.y * -q.y + d.z * -q.z;
+              if (spd > 0.0) specular += pow(spd, m.specular_exponent);
+            }
+          }
+          diffuse = min1(diffuse) * a1;
+          specular = min1(specular) * a2;
+        }
+
+        // A8 sampler
+        double col[3];
+        const int kind = m.sampler_kind;
+        if (kind == RT_SAMPLER_TEXTURE) {
+          const double u = atan2(-n.z, -n.x) / M_PI / 2.0 + 0.5;       // main.js:446 (q6: two divisions)
+          const double v = asin(-n.y) / (M_PI / 2.0) / 2.0 + 0.5;      // main.js:447
+          const rt_texture_desc td = tex[m.texture];
+          const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
+          uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
+          xi = min(xi, td.width - 1u); yi = min(yi, td.height - 1u);   // memory safety only; u,v <= 1
+          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+          col[0] = (double)(texel & 255u) / 255.0; col[1] = (double)((texel >> 8) & 255u) / 255.0;
+          col[2] = (double)((texel >> 16) & 255u) / 255.0;
+          if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
+        } else if (kind == RT_SAMPLER_CHECKER) {
+          const double u = atan2(-n.y, -n.x) / M_PI / 2.0 + 0.5;       // main.js:127 (its own axes)
+          const double v = asin(-n.z) / (M_PI / 2.0) / 2.0 + 0.5;      // main.js:128
+          const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
+          col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
+        } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
+
+        const bool go_r = (rlen != 0.0) && (segs_left > 1);
+        const bool go_f = REFRACT && (flen != 0.0) && (segs_left > 1);
+        if (!go_r && !go_f) {
+          // children are absent or return [0,0,0] (segs == 0, main.js:221): x + 0*a == x
+#pragma unroll
+          for (int c = 0; c < 3; c++) ret[c] = maxa(col[c] * a0, min1(col[c] * diffuse + col[c] * specular));
+        } else {
+          frame<REFRACT> &fr = stack[level];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { fr.amb[c] = col[c] * a0; fr.ds[c] = col[c] * diffuse + col[c] * specular; }
+          fr.a3 = a3;
+          if constexpr (REFRACT) {
+            fr.a4 = a4; fr.h[0] = h.x; fr.h[1] = h.y; fr.h[2] = h.z; fr.f[0] = f.x; fr.f[1] = f.y; fr.f[2] = f.z;
+            fr.re[0] = fr.re[1] = fr.re[2] = 0.0;
+            fr.has_f = go_f; fr.phase = go_r ? 0 : 1;
+          }
+          p = h; d = go_r ? r : f;
+          level++; segs_left--;
+          descend = true;
+        }
+      }
+      if (descend) continue;
+
+      // ---------------- return `ret` to the parents (post-order fold, main.js:268-278, :326-336) ----------------
+      bool resumed = false;
+      while (level > 0) {
+        level--; segs_left++;
+        frame<REFRACT> &fr = stack[level];
+        if constexpr (REFRACT) {
+          if (fr.phase == 0) {
+            fr.re[0] = ret[0] * fr.a3; fr.re[1] = ret[1] * fr.a3; fr.re[2] = ret[2] * fr.a3;
+            if (fr.has_f) {                            // now the refraction child of the same node
+              fr.phase = 1;
+              p = mk(fr.h[0], fr.h[1], fr.h[2]); d = mk(fr.f[0], fr.f[1], fr.f[2]);
+              level++; segs_left--;
+              resumed = true;
+              break;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c]));
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c] + ret[c] * fr.a4));
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + ret[c] * fr.a3));
+        }
+      }
+      if (!resumed) break;
+    }
+  }
+  rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
+}
+
+template <bool REFRACT, bool COUNT, bool SS2>
+__global__ void __launch_bounds__(RT_WG_THREADS) rt_trace(const rt_launch L) {
+  extern __shared__ double lds_raw[];
+  // ---- stage the material table and the texture descriptors into LDS (once per workgroup) ----
+  const uint32_t tid = threadIdx.x;
+  const uint32_t mtl_words = L.n_objects * (uint32_t)(sizeof(rt_sphere) / 8);
+  const uint32_t tex_words = 16u * 2u;               // RT_MAX_TEXTURES descriptors of 16 B
+  for (uint32_t k = tid; k < mtl_words; k += RT_WG_THREADS) lds_raw[k] = ((const double *)L.objects)[k];
+  for (uint32_t k = tid; k < tex_words; k += RT_WG_THREADS) lds_raw[mtl_words + k] = ((const double *)L.textures)[k];
+  __syncthreads();
+  const rt_sphere *mtl = (const rt_sphere *)lds_raw;
+  const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
+
+  // ---- which pixel / sample this work-item owns ----
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const uint32_t tile_x = blockIdx.x % L.tiles_x, tile_y = blockIdx.x / L.tiles_x;
+  uint32_t px, lrow, sub = 0;
+  if (!SS2) { px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); lrow = tile_y * RT_TILE_H + (lane >> 3); }
+  else { const uint32_t q = lane >> 2; sub = lane & 3u; px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); lrow = tile_y * 2u + (q >> 3); }
+  const uint32_t ti = lrow / L.tile_rows;
+  const uint32_t frow = (L.tile_first + ti * L.tile_stride) * L.tile_rows + (lrow - ti * L.tile_rows);
+  const bool valid = (px < L.w) && (ti < L.n_tiles) && (frow < L.h);
+  const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px;
+  const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
+
+  // ---- A1 primary ray (main.js:186-193); dist is indexed by component k, not by axis (q1) ----
+  const double d0 = ((double)sx - L.proj_w) + 0.5, d1 = (L.proj_h - (double)sy) - 0.5, d2 = L.proj_d;
+  const v3 o = mk(L.cam_origin[0], L.cam_origin[1], L.cam_origin[2]);
+  const v3 target = mk(o.x + L.cam_axis_x[0] * d0 + L.cam_axis_y[0] * d0 + L.cam_axis_z[0] * d0,
+                       o.y + L.cam_axis_x[1] * d1 + L.cam_axis_y[1] * d1 + L.cam_axis_z[1] * d1,
+                       o.z + L.cam_axis_x[2] * d2 + L.cam_axis_y[2] * d2 + L.cam_axis_z[2] * d2);
+  double rl;
+  const v3 ray = unit(mk(target.x - o.x, target.y - o.y, target.z - o.z), &rl);
+
+  double rgb[3];
+  uint32_t cnt[3] = {0u, 0u, 0u};
+  trace_pixel<REFRACT, COUNT>(L, mtl, tex, o, ray, rgb, cnt);
+
+  // ---- A10 RGBA8 store ----
+  const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
+  if (!SS2) {
+    if (valid) L.out[(size_t)lrow * L.w + px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+  } else {
+    // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields)
+    uint32_t packed = r8 | (g8 << 10) | (b8 << 20);
+    packed += __shfl_xor(packed, 1);
+    packed += __shfl_xor(packed, 2);
+    const uint32_t R = ((packed & 1023u) + 2u) >> 2, G = (((packed >> 10) & 1023u) + 2u) >> 2, B = (((packed >> 20) & 1023u) + 2u) >> 2;
+    if (valid && sub == 0u) L.out[(size_t)lrow * L.w + px] = R | (G << 8) | (B << 16) | 0xff000000u;
+  }
+
+  if (COUNT) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      unsigned long long v = valid ? cnt[c] : 0u;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) atomicAdd(&L.counters[c], v);
+    }
+  }
+}
+
+}  // namespace
+
+// Host-side launcher for this translation unit's kernels.  Returns a hipError_t as int.
+extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned grid_blocks, unsigned lds_bytes,
+                              hipStream_t stream) {
+  const dim3 grid(grid_blocks), block(RT_WG_THREADS);
+#define RT_CASE(R, C, S) hipLaunchKernelGGL((rt_trace<R, C, S>), grid, block, lds_bytes, stream, *L)
+  if (!count) {
+    if (!refract) { if (!ss2) RT_CASE(false, false, false); else RT_CASE(false, false, true); }
+    else          { if (!ss2) RT_CASE(true, false, false);  else RT_CASE(true, false, true); }
+  } else {
+    if (!refract) { if (!ss2) RT_CASE(false, true, false); else RT_CASE(false, true, true); }
+    else          { if (!ss2) RT_CASE(true, true, false);  else RT_CASE(true, true, true); }
+  }
+#undef RT_CASE
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,141 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+import oracle_util as ou
+import rt_host
+
+ROOT = ou.ROOT
+needs_node = pytest.mark.skipif(ou.node_path() is None, reason="node not installed")
+SCENE_NAMES = ["cfg1", "cfg2", "h8", "h8_d8", "default14", "lcg64", "lcg64_ss1"]
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    body = header[header.index("/* Library lifetime."):]      # prototypes follow the type declarations
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", body))
+    assert declared == set(rt_host.ABI), declared ^ set(rt_host.ABI)
+    lib = rt_host.load_library()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rt_abi_version() == rt_host.RT_ABI_VERSION
+
+
+def test_struct_sizes_match_header(built):
+    assert C.sizeof(rt_host.RtTiles) == 16 and C.sizeof(rt_host.RtStats) == 48
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    magic, ver, total = struct.unpack_from("<IIQ", blob, 0)
+    assert (magic, ver, total) == (rt_host.RT_SCENE_MAGIC, 1, len(blob))
+    assert len(blob) == 208 + 8 * 192 + 2 * 24 + 2 * 16 + 2 * 131072
+
+
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_validate_accepts_good_scenes(name, built):
+    lib = rt_host.load_library()
+    blob = rt_host.flatten_scene(rt_host.load_scene(name))
+    buf = C.create_string_buffer(blob, len(blob))
+    assert lib.rt_scene_validate(buf, len(blob)) == 0, lib.rt_last_error()
+
+
+def test_validate_rejects_bad_blobs(built):
+    lib = rt_host.load_library()
+    good = bytearray(rt_host.flatten_scene(rt_host.load_scene("cfg2")))
+
+    def check(mutate, code, needle):
+        b = bytearray(good)
+        mutate(b)
+        buf = C.create_string_buffer(bytes(b), len(b))
+        assert lib.rt_scene_validate(buf, len(b)) == code
+        assert needle in lib.rt_last_error().decode()
+
+    check(lambda b: struct.pack_into("<I", b, 0, 0xdeadbeef), -1, "magic")
+    check(lambda b: struct.pack_into("<I", b, 4, 7), -1, "ABI version")
+    check(lambda b: struct.pack_into("<Q", b, 8, len(b) + 8), -1, "total_bytes")
+    check(lambda b: struct.pack_into("<I", b, 160, 99), -1, "segs")
+    check(lambda b: struct.pack_into("<I", b, 168, 0), -1, "n_objects")
+    check(lambda b: struct.pack_into("<Q", b, 184, len(b) - 8), -1, "object table")
+    # sampler kind 3 = the reference's Math.random stars sampler: explicit error, not silence
+    check(lambda b: struct.pack_into("<i", b, 208 + 176, 3), -2, "stars sampler")
+    check(lambda b: struct.pack_into("<i", b, 208 + 0 * 192 + 180, 9), -1, "texture index")
+    buf = C.create_string_buffer(bytes(good[:100]), 100)
+    assert lib.rt_scene_validate(buf, 100) == -1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    """Without a GPU the render entry points must fail with RT_ERR_DEVICE / RT_ERR_STATE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt_host.RtError, match="no HIP device|rt_init"):
+        rt_host.render(16, 16, rt_host.load_scene("cfg1"))
+
+
+def test_python_host_rejects_unsupported_sampler():
+    s = rt_host.load_scene("cfg1")
+    s["objects"][0]["mtl"]["sampler"] = {"kind": 3}
+    with pytest.raises(ValueError, match="stars"):
+        rt_host.flatten_scene(s)
+
+
+@needs_node
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_js_and_python_flatteners_agree(name, tmp_path):
+    out = tmp_path / "scene.blob"
+    r = ou.node_cli("flatten", ou.scene_json(name), "--out", out)
+    blob = rt_host.flatten_scene(rt_host.load_scene(name))
+    assert r["bytes"] == len(blob)
+    assert hashlib.sha256(blob).hexdigest() == r["sha256"]
+
+
+JS_PIPELINE = r"""
+const S = require('%(pkg)s/js/scene.js'), SC = require('%(pkg)s/js/scenes.js'), P = require('%(pkg)s/js/png.js');
+const zlib = require('zlib');
+const cam = S.lookAt([0,1.5,10],[0,1.5,0],[0,1,0]);
+const tex = {earth: S.textureFromRGBA(2,1,new Uint8Array(8)), mars: S.textureFromRGBA(2,1,new Uint8Array(8))};
+const sc = SC.default14(tex);
+const order = sc.objects.map(o => o.origin.join(','));
+const ck = S.checkerTexture(S.createTexture(), 16, 8, [0,0,0], [1,1,1]);
+// hand-made 2x2 RGBA PNG with filter types 0 (None) and 1 (Sub)
+function crc(buf){let c,t=[];for(let n=0;n<256;n++){c=n;for(let k=0;k<8;k++)c=c&1?0xedb88320^(c>>>1):c>>>1;t[n]=c>>>0;}c=0xffffffff;for(const b of buf)c=t[(c^b)&255]^(c>>>8);return (c^0xffffffff)>>>0;}
+function chunk(type,data){const b=Buffer.concat([Buffer.from(type),data]);const o=Buffer.alloc(12+data.length);o.writeUInt32BE(data.length,0);b.copy(o,4);o.writeUInt32BE(crc(b),8+data.length);return o;}
+const ihdr=Buffer.alloc(13);ihdr.writeUInt32BE(2,0);ihdr.writeUInt32BE(2,4);ihdr[8]=8;ihdr[9]=6;
+const raw=Buffer.from([0, 10,20,30,255, 40,50,60,128,  1, 1,2,3,4, 1,1,1,1]);
+const png=Buffer.concat([Buffer.from([0x89,0x50,0x4e,0x47,0x0d,0x0a,0x1a,0x0a]),chunk('IHDR',ihdr),chunk('IDAT',zlib.deflateSync(raw)),chunk('IEND',Buffer.alloc(0))]);
+const img=P.decodePNG(png);
+let threw=false; try { const m=S.createMaterial([1,1,1],[1,0,0,0,0],0,1); m.sampler=function(){}; S.createScene({objects:[S.createSphere([0,0,0],1,m)]}); } catch(e){threw=/closures/.test(e.message);}
+console.log(JSON.stringify({cam, order, ck: Array.from(ck.texels.slice(0,12)), img: Array.from(img.data), threw}));
+"""
+
+
+@needs_node
+def test_js_host_scene_pipeline(tmp_path):
+    """constructors, sort order (q4), lookAt, checker texture, PNG decode."""
+    script = tmp_path / "t.js"
+    script.write_text(JS_PIPELINE % {"pkg": os.path.join(ROOT, "html5-canvas-raytracer_amd")})
+    out = json.loads(subprocess.check_output([ou.node_path(), str(script)], text=True))
+    # main.js:92-100 with the default arguments gives the mirrored frame of quirk q1
+    assert out["cam"]["axisX"] == [-1, 0, 0] and out["cam"]["axisY"] == [0, 1, 0] and out["cam"]["axisZ"] == [0, 0, -1]
+    # chrome(1,.25,3), matte, mirror, chrome(1.5,2.5,0), metal, mars, glass, bubble, blue, red, green, earth, home, skybox
+    assert out["order"] == ["1,0.25,3", "0,0.25,3", "0,2.5,-2", "1.5,2.5,0", "-1.5,2.5,0", "-50,20,-100", "-2.5,0.5,3", "2.5,0.5,3",
+                            "0,1,-2", "-1.5,1,0", "1.5,1,0", "50,20,-100", "0,-500,0", "0,0,0"]
+    assert out["ck"] == [0, 0, 0, 255, 255, 255, 255, 255, 0, 0, 0, 255]
+    assert out["img"] == [10, 20, 30, 255, 40, 50, 60, 128, 1, 2, 3, 4, 2, 3, 4, 5]
+    assert out["threw"]
+
+
+@pytest.mark.skipif(not ou.have_reference(), reason="/root/reference not present")
+@pytest.mark.reference
+def test_png_decoder_matches_pil_on_reference_textures():
+    from PIL import Image
+    import numpy as np
+    for n in ("earth", "mars"):
+        pil = np.asarray(Image.open(os.path.join(ou.REFERENCE_DIR, n + ".png")).convert("RGBA")).tobytes()
+        ours = open(os.path.join(ou.SCENES, n + "_256x128.rgba"), "rb").read()
+        assert pil == ours
