@@ -110,7 +110,12 @@ def main():
     n_tiles = (h + TILE_ROWS - 1) // TILE_ROWS
     per_rank = (n_tiles + world - 1) // world
     band_rows = per_rank * TILE_ROWS
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
+    # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     if world == 1:
         frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
         bands = None

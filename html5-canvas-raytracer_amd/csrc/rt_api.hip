@@ -78,6 +78,7 @@ struct rt_scene_dev {
   int device;
   void *d_blob;                  // the uploaded scene blob
   rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
+  rt_geom *d_geom;               // compact geometry table (origin, r2) for the scalar-loaded loops
   rt_scene_header hd;            // host copy
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
   unsigned lds_bytes;
@@ -153,7 +154,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if ((rc = ensure_device(device))) return rc;
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
-  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr;
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -164,13 +165,18 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   rt_texture_desc descs[RT_MAX_TEXTURES];
   memset(descs, 0, sizeof descs);
   if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
+  std::vector<rt_geom> geom(hd->n_objects);
+  for (uint32_t i = 0; i < hd->n_objects; i++) geom[i] = rt_geom{ob[i].origin[0], ob[i].origin[1], ob[i].origin[2], ob[i].r2};
   hipError_t e = hipMalloc(&s->d_blob, bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
+  if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_blob, blob, bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_texdesc, descs, sizeof descs, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (s->d_blob) (void)hipFree(s->d_blob);
     if (s->d_texdesc) (void)hipFree(s->d_texdesc);
+    if (s->d_geom) (void)hipFree(s->d_geom);
     delete s;
     return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
   }
@@ -183,6 +189,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (G.inited && s->device < (int)G.dev.size()) (void)hipSetDevice(G.dev[s->device].hip_id);
   (void)hipFree(s->d_blob);
   (void)hipFree(s->d_texdesc);
+  (void)hipFree(s->d_geom);
   delete s;
 }
 
@@ -206,6 +213,7 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   const uint8_t *db = (const uint8_t *)s->d_blob;
   L.objects = (const rt_sphere *)(db + hd.objects_offset);
   L.textures = s->d_texdesc;
+  L.geom = s->d_geom;
   L.texel_base = db;
   L.out = (uint32_t *)d_out;
   L.counters = D.d_counters;

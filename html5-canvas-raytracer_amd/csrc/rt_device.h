@@ -13,11 +13,15 @@
 #define RT_TILE_W 32
 #define RT_TILE_H 8
 
+// Sphere geometry as the uniform object loops read it: 32 bytes, scalar-loaded (s_load_dwordx8).
+struct rt_geom { double ox, oy, oz, r2; };
+
 // Everything one launch needs, passed by value in the kernarg segment (scalar-loaded into
 // SGPRs: all of it is wave-uniform).
 struct rt_launch {
   // resident scene (HBM)
-  const rt_sphere *objects;          // n_objects records of 192 B; geometry = first 32 B of each
+  const rt_sphere *objects;          // n_objects records of 192 B (materials; staged into LDS per workgroup)
+  const rt_geom *geom;               // n_objects compact geometry records for the scalar-loaded loops
   const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`
   const uint8_t *texel_base;
   uint32_t *out;                     // RGBA8 packed little-endian (R in the low byte)

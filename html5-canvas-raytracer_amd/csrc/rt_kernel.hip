@@ -47,6 +47,11 @@
 #define RT_LAUNCH_NAME rt_launch_trace_fast
 #endif
 
+// Register budget: minimum waves per SIMD the kernel must fit (second __launch_bounds__ argument).
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 2
+#endif
+
 #define RT_INF __builtin_inf()
 
 namespace {
@@ -55,6 +60,20 @@ struct v3 { double x, y, z; };
 __device__ __forceinline__ v3 mk(double x, double y, double z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 // main.js:49-51 — (a0*b0 + a1*b1) + a2*b2
 __device__ __forceinline__ double dot(const v3 a, const v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// ---- math layer ----------------------------------------------------------------------------
+// RT_STRICT: IEEE-754 correctly rounded sqrt and division and OCML pow, operation for operation
+// with the JS expression trees.  Otherwise (product kernel): the hardware estimates v_rsq_f64 /
+// v_rcp_f64 refined by Newton steps in FMA arithmetic (<= ~1 ulp, no denormal pre-scaling, no
+// div_scale/div_fixup), reciprocal-multiplies for divisions by constants, and integer powers by
+// square-and-multiply.  All of it stays binary64; the differences are last-ulp effects, which
+// the +-1 LSB tolerance exists for (tests/test_gpu_parity.py holds both kernels to it).
+#if RT_STRICT
+__device__ __forceinline__ double rt_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double rt_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double rt_div(double a, double b) { return a / b; }
+__device__ __forceinline__ double rt_pow(double x, double e) { return pow(x, e); }
+#define RT_DIV_CONST(x, c) ((x) / (c))
 // main.js:62-66 — multiply by 1/len; the zero vector is returned unchanged
 __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
   const double l = sqrt(dot(v, v));
@@ -62,6 +81,57 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
   if (l != 0.0) { const double s = 1.0 / l; return mk(v.x * s, v.y * s, v.z * s); }
   return v;
 }
+#else
+__device__ __forceinline__ double rt_rsqrt_pos(double m) {           // m > 0, finite
+  double y = __builtin_amdgcn_rsq(m);
+  double e = __builtin_fma(-(m * y), y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-(m * y), y, 1.0);
+  return __builtin_fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double rt_sqrt(double x) {
+  const double y = rt_rsqrt_pos(x);
+  double g = x * y;
+  g = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
+  return (x > 0.0) ? g : x;                                           // +0 -> 0, NaN -> NaN, x < 0 -> x (callers never pass it)
+}
+__device__ __forceinline__ double rt_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ double rt_div(double a, double b) {
+  const double r = rt_rcp(b);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-q, b, a), r, q);               // one correction step on the quotient
+}
+#define RT_DIV_CONST(x, c) rt_div_const((x), (c), 1.0 / (c))
+__device__ __forceinline__ double rt_div_const(double a, double c, double rc) {
+  const double q = a * rc;
+  return __builtin_fma(__builtin_fma(-q, c, a), rc, q);
+}
+// x > 0.  Integer exponents (every specular_exponent of the reference scene, main.js:108-123) by
+// square-and-multiply: <= 2*log2(e) multiplies instead of OCML's ~150-instruction pow.
+__device__ __forceinline__ double rt_pow(double x, double e) {
+  const int n = (int)e;
+  if ((double)n == e && n >= 0 && n <= 65536) {
+    double r = 1.0, b = x;
+    unsigned k = (unsigned)n;
+    while (k) { if (k & 1u) r *= b; b *= b; k >>= 1; }
+    return r;
+  }
+  return pow(x, e);
+}
+// main.js:62-66 — v * (1/len), len = sqrt(v.v); the zero vector is returned unchanged
+__device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
+  const double m = dot(v, v);
+  const double s = rt_rsqrt_pos(m);
+  const bool ok = (m > 0.0);
+  *len_out = ok ? m * s : m;
+  return ok ? mk(v.x * s, v.y * s, v.z * s) : v;
+}
+#endif
+
 // main.js:40-43 — v + n * (-(2 * v.n))
 __device__ __forceinline__ v3 reflect(const v3 v, const v3 n) {
   const double t = -(2.0 * dot(v, n));
@@ -90,15 +160,14 @@ __device__ __forceinline__ uint32_t to_byte(double c) {
 // main.js:420-439.  Returns the nearest root >= eps (Infinity on a miss; NaN passes through and
 // loses every later comparison, exactly as in the reference); *inside = (t0 < eps), which for a
 // returned root equals the reference's (t0 < 0.001) || (t1 < 0.001) because t0 <= t1.
-__device__ __forceinline__ double isect(const double ox, const double oy, const double oz, const double r2,
-                                        const v3 p, const v3 d, const double eps, bool *inside) {
-  const v3 L = mk(ox - p.x, oy - p.y, oz - p.z);
+__device__ __forceinline__ double isect(const rt_geom g, const v3 p, const v3 d, const double eps, bool *inside) {
+  const v3 L = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
   const double tca = dot(d, L);
   const double d2 = dot(L, L) - tca * tca;
   double t = RT_INF;
   *inside = false;
-  if (!(d2 > r2)) {                                  // wave-wide skip of the sqrt path on a full miss
-    const double thc = sqrt(r2 - d2);
+  if (!(d2 > g.r2)) {                                // wave-wide skip of the sqrt path on a full miss
+    const double thc = rt_sqrt(g.r2 - d2);
     const double t0 = tca - thc, t1 = tca + thc;
     // thc >= 0 (or NaN), so t0 <= t1: both arms of the reference's if (t0 < t1) select the same value
     t = (t0 < eps) ? ((t1 < eps) ? RT_INF : t1) : t0;
@@ -118,6 +187,7 @@ template <bool REFRACT, bool COUNT>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
   const rt_sphere *__restrict__ objs = L.objects;
+  const rt_geom *__restrict__ geom = L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
   const double eps = L.epsilon;
   frame<REFRACT> stack[RT_MAX_SEGS];
@@ -130,15 +200,22 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // ---------------- evaluate one intersectWorld node (segs_left > 0 here) ----------------
       if (COUNT) cnt[0]++;
       // A3: closest hit.  Uniform trip count, sphere geometry via scalar loads.
-      double ht = RT_INF; int hi = -1; bool inside = false;
+      // The winner is kept as one int, 2*i + inside, so a candidate costs one 64-bit and one
+      // 32-bit select.
+      double ht = RT_INF; int hcode = -1;
+#pragma unroll 2
       for (uint32_t i = 0; i < N; i++) {
         bool in;
-        const double t = isect(objs[i].origin[0], objs[i].origin[1], objs[i].origin[2], objs[i].r2, p, d, eps, &in);
-        if (t < ht) { ht = t; hi = (int)i; inside = in; }
+        const double t = isect(geom[i], p, d, eps, &in);
+        const int code = (int)(2u * i) + (in ? 1 : 0);
+        const bool closer = (t < ht);
+        ht = closer ? t : ht; hcode = closer ? code : hcode;
       }
       if (COUNT) cnt[2] += N;
+      const int hi = hcode >> 1;
+      const bool inside = (hcode & 1) != 0;
       bool descend = false;
-      if (hi < 0) {                                   // main.js:231
+      if (hcode < 0) {                                // main.js:231
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
       } else {
         const rt_sphere &m = mtl[hi];                 // LDS, per-lane index
@@ -160,10 +237,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           double cosi = -((dn < -1.0) ? -1.0 : min1(dn));              // -Math.max(-1, Math.min(1, dot))
           v3 nn = n; double eta;
           if (cosi < 0.0) { cosi = -cosi; nn = mk(-n.x, -n.y, -n.z); eta = m.refract_index; }
-          else eta = 1.0 / m.refract_index;
+          else eta = rt_rcp(m.refract_index);
           const double k = 1.0 - eta * eta * (1.0 - cosi * cosi);
           if (k > 0.0) {
-            const double q = eta * cosi - sqrt(k);
+            const double q = eta * cosi - rt_sqrt(k);
             f = mk(d.x * eta + nn.x * q, d.y * eta + nn.y * q, d.z * eta + nn.z * q);
           } else f = reflect(d, nn);                                   // total internal reflection
           f = unit(f, &flen);
@@ -181,26 +258,28 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             const double sdot = dot(sv, l);
             if (sdot <= 0.0) continue;                                 // surface faces away
             if (COUNT) cnt[1]++;
+            // Shadow scan (main.js:293-304).  `alive` is the per-lane "not yet fully blocked" flag; the
+            // loop leaves early only when every lane of the wave is blocked (exec-mask loop exit).
             uint32_t tests = 0;
             for (uint32_t j = 0; j < N; j++) {
               if ((int)j == hi) continue;                              // main.js:294 (q3)
               bool in;
-              const double t = isect(objs[j].origin[0], objs[j].origin[1], objs[j].origin[2], objs[j].r2, h, sv, eps, &in);
+              const double t = isect(geom[j], h, sv, eps, &in);
               tests++;
               if (t < llen) {
                 const double oa4 = objs[j].albedo[4];
-                if (oa4 != 0.0) li /= oa4;                             // transparent occluder brightens (q2)
+                if (oa4 != 0.0) li = rt_div(li, oa4);                  // transparent occluder brightens (q2)
                 else { li = 0.0; break; }
               }
             }
             if (COUNT) cnt[2] += tests;
             if (li == 0.0) continue;
-            diffuse += li * sdot / lmag;
+            diffuse += rt_div(li * sdot, lmag);
             if (a2 > 0.0) {
               double ql;
               const v3 q = unit(reflect(mk(-sv.x, -sv.y, -sv.z), l), &ql);
               const double spd = d.x * -q.x + d.y * -q.y + d.z * -q.z;
-              if (spd > 0.0) specular += pow(spd, m.specular_exponent);
+              if (spd > 0.0) specular += rt_pow(spd, m.specular_exponent);
             }
           }
           diffuse = min1(diffuse) * a1;
@@ -211,19 +290,19 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         double col[3];
         const int kind = m.sampler_kind;
         if (kind == RT_SAMPLER_TEXTURE) {
-          const double u = atan2(-n.z, -n.x) / M_PI / 2.0 + 0.5;       // main.js:446 (q6: two divisions)
-          const double v = asin(-n.y) / (M_PI / 2.0) / 2.0 + 0.5;      // main.js:447
+          const double u = RT_DIV_CONST(atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
+          const double v = RT_DIV_CONST(asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
           const rt_texture_desc td = tex[m.texture];
           const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
           uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
           xi = min(xi, td.width - 1u); yi = min(yi, td.height - 1u);   // memory safety only; u,v <= 1
           const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
-          col[0] = (double)(texel & 255u) / 255.0; col[1] = (double)((texel >> 8) & 255u) / 255.0;
-          col[2] = (double)((texel >> 16) & 255u) / 255.0;
+          col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
+          col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
           if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
         } else if (kind == RT_SAMPLER_CHECKER) {
-          const double u = atan2(-n.y, -n.x) / M_PI / 2.0 + 0.5;       // main.js:127 (its own axes)
-          const double v = asin(-n.z) / (M_PI / 2.0) / 2.0 + 0.5;      // main.js:128
+          const double u = RT_DIV_CONST(atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
+          const double v = RT_DIV_CONST(asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
           col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
         } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
@@ -284,7 +363,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 }
 
 template <bool REFRACT, bool COUNT, bool SS2>
-__global__ void __launch_bounds__(RT_WG_THREADS) rt_trace(const rt_launch L) {
+__global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const rt_launch L) {
   extern __shared__ double lds_raw[];
   // ---- stage the material table and the texture descriptors into LDS (once per workgroup) ----
   const uint32_t tid = threadIdx.x;

@@ -18,7 +18,7 @@ import struct
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SCENES_DIR = os.path.join(HERE, "scenes")
-LIB_PATH = os.path.join(HERE, "csrc", "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(HERE, "csrc", "librt_hip.so")   # RT_HIP_LIB: A/B builds
 
 RT_SCENE_MAGIC = 0x31535452
 RT_ABI_VERSION = 1

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs of run_profile.sh into the small summaries committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, summ, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(summ, exist_ok=True)
+lines = []
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+# ---- kernel trace: per-kernel durations
+for f in find("trace/**/*kernel_stats.csv"):
+    lines.append("== kernel stats (%s) ==" % os.path.relpath(f, out))
+    lines += [l.rstrip() for l in open(f)]
+durs = defaultdict(list)
+for f in find("trace/**/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
+lines.append("")
+lines.append("== per-kernel durations from the kernel trace ==")
+kern = {}
+for k, v in sorted(durs.items(), key=lambda kv: -sum(d for d, _ in kv[1])):
+    d = [x for x, _ in v]
+    r = v[0][1]
+    kern[k] = {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+    lines.append("%-90s calls=%d avg=%.1f us min=%.1f us max=%.1f us  VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s" % (
+        k[:90], len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
+        r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+
+# ---- counters: average per dispatch of the trace kernel
+pmc = defaultdict(lambda: defaultdict(list))
+for f in find("pmc_*/**/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines.append("")
+lines.append("== PMC counters, average per dispatch ==")
+counters = {}
+for k, cs in pmc.items():
+    if "rt_trace" not in k:
+        continue
+    lines.append(k[:120])
+    for c, v in sorted(cs.items()):
+        counters[c] = sum(v) / len(v)
+        lines.append("   %-28s %18.1f  (n=%d)" % (c, counters[c], len(v)))
+open(os.path.join(summ, "%s_rocprof_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+json.dump({"kernels": kern, "rt_trace_counters_per_dispatch": counters}, open(os.path.join(summ, "%s_rocprof_summary.json" % tag), "w"), indent=1)
+print("\n".join(lines[-60:]))
