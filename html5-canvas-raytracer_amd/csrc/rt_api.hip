@@ -165,8 +165,18 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   rt_texture_desc descs[RT_MAX_TEXTURES];
   memset(descs, 0, sizeof descs);
   if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
-  std::vector<rt_geom> geom(hd->n_objects);
-  for (uint32_t i = 0; i < hd->n_objects; i++) geom[i] = rt_geom{ob[i].origin[0], ob[i].origin[1], ob[i].origin[2], ob[i].r2};
+  // geometry tables: [0,N) plain, [N,2N) anchored at the camera, [2N, 2N + NL*N) anchored at each light
+  const uint32_t NO = hd->n_objects;
+  std::vector<rt_geom> geom((size_t)NO * (2 + hd->n_lights));
+  auto anchored = [&](const rt_sphere &o, const double a[3]) {
+    const double lx = o.origin[0] - a[0], ly = o.origin[1] - a[1], lz = o.origin[2] - a[2];
+    return rt_geom{lx, ly, lz, (lx * lx + ly * ly + lz * lz) - o.r2};
+  };
+  for (uint32_t i = 0; i < NO; i++) {
+    geom[i] = rt_geom{ob[i].origin[0], ob[i].origin[1], ob[i].origin[2], ob[i].r2};
+    geom[NO + i] = anchored(ob[i], hd->cam_origin);
+    for (uint32_t k = 0; k < hd->n_lights; k++) geom[(size_t)NO * (2 + k) + i] = anchored(ob[i], s->lights[k]);
+  }
   hipError_t e = hipMalloc(&s->d_blob, bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
@@ -214,6 +224,8 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.objects = (const rt_sphere *)(db + hd.objects_offset);
   L.textures = s->d_texdesc;
   L.geom = s->d_geom;
+  L.geom_cam = s->d_geom + hd.n_objects;
+  L.geom_light = s->d_geom + 2 * (size_t)hd.n_objects;
   L.texel_base = db;
   L.out = (uint32_t *)d_out;
   L.counters = D.d_counters;

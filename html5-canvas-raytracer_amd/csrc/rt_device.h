@@ -22,6 +22,8 @@ struct rt_launch {
   // resident scene (HBM)
   const rt_sphere *objects;          // n_objects records of 192 B (materials; staged into LDS per workgroup)
   const rt_geom *geom;               // n_objects compact geometry records for the scalar-loaded loops
+  const rt_geom *geom_cam;           // anchored at the camera: {o - cam, |o - cam|^2 - r2} per sphere
+  const rt_geom *geom_light;         // anchored at light k: [k*n_objects + j] = {o_j - light_k, |o_j - light_k|^2 - r2_j}
   const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`
   const uint8_t *texel_base;
   uint32_t *out;                     // RGBA8 packed little-endian (R in the low byte)

@@ -70,6 +70,7 @@ __device__ __forceinline__ double dot(const v3 a, const v3 b) { return a.x * b.x
 // the +-1 LSB tolerance exists for (tests/test_gpu_parity.py holds both kernels to it).
 #if RT_STRICT
 __device__ __forceinline__ double rt_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double rt_sqrt_nn(double x) { return sqrt(x); }
 __device__ __forceinline__ double rt_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ double rt_div(double a, double b) { return a / b; }
 __device__ __forceinline__ double rt_pow(double x, double e) { return pow(x, e); }
@@ -94,6 +95,17 @@ __device__ __forceinline__ double rt_sqrt(double x) {
   double g = x * y;
   g = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
   return (x > 0.0) ? g : x;                                           // +0 -> 0, NaN -> NaN, x < 0 -> x (callers never pass it)
+}
+// x >= 0 (or NaN): the +0 case is kept exact by clamping the estimate (rsq(0) = inf) instead of
+// selecting afterwards: 0 * 1e100 = 0 through every step below.
+__device__ __forceinline__ double rt_sqrt_nn(double x) {
+  double y = __builtin_fmin(__builtin_amdgcn_rsq(x), 1e100);
+  double e = __builtin_fma(-(x * y), y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-(x * y), y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  const double g = x * y;
+  return __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
 }
 __device__ __forceinline__ double rt_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -157,24 +169,27 @@ __device__ __forceinline__ uint32_t to_byte(double c) {
   return (uint32_t)rint(v);
 }
 
-// main.js:420-439.  Returns the nearest root >= eps (Infinity on a miss; NaN passes through and
-// loses every later comparison, exactly as in the reference); *inside = (t0 < eps), which for a
-// returned root equals the reference's (t0 < 0.001) || (t1 < 0.001) because t0 <= t1.
-__device__ __forceinline__ double isect(const rt_geom g, const v3 p, const v3 d, const double eps, bool *inside) {
-  const v3 L = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
-  const double tca = dot(d, L);
-  const double d2 = dot(L, L) - tca * tca;
-  double t = RT_INF;
-  *inside = false;
-  if (!(d2 > g.r2)) {                                // wave-wide skip of the sqrt path on a full miss
-    const double thc = rt_sqrt(g.r2 - d2);
-    const double t0 = tca - thc, t1 = tca + thc;
-    // thc >= 0 (or NaN), so t0 <= t1: both arms of the reference's if (t0 < t1) select the same value
-    t = (t0 < eps) ? ((t1 < eps) ? RT_INF : t1) : t0;
-    *inside = (t0 < eps);
-  }
-  return t;
-}
+// main.js:420-439, as a "candidate root" test.  With thc >= 0 (or NaN) the reference's two-armed
+// root selection reduces to: cand = (t0 < eps) ? t1 : t0, and the sphere is hit at cand unless
+// cand < eps (both roots behind the epsilon).  NaN fails every comparison, exactly as it loses
+// `check.t < hit.t` / `t < light_len` in the reference.  inside = (t0 < eps), which for an
+// accepted root equals the reference's (t0 < 0.001) || (t1 < 0.001) (main.js:445).
+//
+// Two forms of the line-sphere discriminant:
+//   generic  (any origin p):     L = o - p, tca = d.L, d2 = L.L - tca^2, miss if d2 > r2   — the reference's own
+//   anchored (uniform origin a): the host precomputes La = o - a and Ca = La.La - r2 per sphere; then
+//            tca = d.La and r2 - d2 = tca^2 - Ca: 4 operations instead of 10.  Used (product kernel only)
+//            for primary rays (a = camera) and for shadow rays walked FROM the light (a = light k), whose
+//            line is the same line, so the same discriminant decides hit or miss.
+// Both helpers must be called inside `if (hit)`; RT_PIN keeps the bookkeeping in that branch so that a
+// wave whose 64 rays all miss pays one s_cbranch_execz and nothing else.
+#define RT_PIN() asm volatile("")
+
+// The scene tables walked by the wave-uniform loops live in global memory that nothing writes
+// during the launch.  Typing them as CONSTANT address space (4) makes every uniform-index read an
+// s_load into SGPRs by construction, whatever else is in the loop.
+typedef const rt_geom __attribute__((address_space(4))) *geom_kptr;
+typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 
 // A frame of the explicit recursion stack: everything intersectWorld still needs after its
 // recursive calls return (main.js:320-336) — the lighting and sampler terms do not depend on the
@@ -186,14 +201,15 @@ template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3
 template <bool REFRACT, bool COUNT>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
-  const rt_sphere *__restrict__ objs = L.objects;
-  const rt_geom *__restrict__ geom = L.geom;
+  const sphere_kptr objs = (sphere_kptr)L.objects;
+  const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
   const double eps = L.epsilon;
   frame<REFRACT> stack[RT_MAX_SEGS];
   int level = 0;
   uint32_t segs_left = L.segs;
   double ret[3] = {0.0, 0.0, 0.0};
+  [[maybe_unused]] bool primary = true;                 // the first node evaluated is the primary ray (origin = camera, uniform)
 
   if (segs_left != 0) {
     for (;;) {
@@ -203,14 +219,48 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // The winner is kept as one int, 2*i + inside, so a candidate costs one 64-bit and one
       // 32-bit select.
       double ht = RT_INF; int hcode = -1;
+#if !RT_STRICT
+      if (level == 0 && primary) {
+        // primary rays: anchored at the camera
+        const geom_kptr ga = (geom_kptr)L.geom_cam;
 #pragma unroll 2
-      for (uint32_t i = 0; i < N; i++) {
-        bool in;
-        const double t = isect(geom[i], p, d, eps, &in);
-        const int code = (int)(2u * i) + (in ? 1 : 0);
-        const bool closer = (t < ht);
-        ht = closer ? t : ht; hcode = closer ? code : hcode;
+        for (uint32_t i = 0; i < N; i++) {
+          const rt_geom g = {ga[i].ox, ga[i].oy, ga[i].oz, ga[i].r2};
+          const double tca = d.x * g.ox + d.y * g.oy + d.z * g.oz;
+          const double disc = __builtin_fma(tca, tca, -g.r2);        // r2 - d2
+          if (!(disc < 0.0)) {
+            RT_PIN();
+            const double thc = rt_sqrt_nn(disc);
+            const double t0 = tca - thc, t1 = tca + thc;
+            const bool in = (t0 < eps);
+            const double t = in ? t1 : t0;
+            const bool closer = (t < ht) && !(t < eps);               // strict <: first wins
+            ht = closer ? t : ht;
+            hcode = closer ? ((int)(2u * i) + (in ? 1 : 0)) : hcode;
+          }
+        }
+      } else
+#endif
+      {
+#pragma unroll 2
+        for (uint32_t i = 0; i < N; i++) {
+          const rt_geom g = {geom[i].ox, geom[i].oy, geom[i].oz, geom[i].r2};
+          const v3 Lv = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
+          const double tca = dot(d, Lv);
+          const double d2 = dot(Lv, Lv) - tca * tca;
+          if (!(d2 > g.r2)) {
+            RT_PIN();
+            const double thc = rt_sqrt_nn(g.r2 - d2);
+            const double t0 = tca - thc, t1 = tca + thc;
+            const bool in = (t0 < eps);
+            const double t = in ? t1 : t0;
+            const bool closer = (t < ht) && !(t < eps);               // strict <: first wins
+            ht = closer ? t : ht;
+            hcode = closer ? ((int)(2u * i) + (in ? 1 : 0)) : hcode;
+          }
+        }
       }
+      primary = false;
       if (COUNT) cnt[2] += N;
       const int hi = hcode >> 1;
       const bool inside = (hcode & 1) != 0;
@@ -227,12 +277,35 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
         const double a4 = REFRACT ? m.albedo[4] : 0.0;
 
+        // A8 sampler (main.js:320).  Pure, so it is evaluated here, before the lighting, where few values
+        // are live: the OCML atan2/asin bodies are the register-pressure peak of the kernel.
+        double col[3];
+        const int kind = m.sampler_kind;
+        if (kind == RT_SAMPLER_TEXTURE) {
+          const double u = RT_DIV_CONST(atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
+          const double v = RT_DIV_CONST(asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
+          const rt_texture_desc td = tex[m.texture];
+          const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
+          uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
+          xi = min(xi, td.width - 1u); yi = min(yi, td.height - 1u);   // memory safety only; u,v <= 1
+          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+          col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
+          col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
+          if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
+        } else if (kind == RT_SAMPLER_CHECKER) {
+          const double u = RT_DIV_CONST(atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
+          const double v = RT_DIV_CONST(asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
+          const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
+          col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
+        } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
+
         // A4 reflection direction
         v3 r = mk(0, 0, 0); double rlen = 0.0;
-        if (a3 > 0.0) r = unit(reflect(d, n), &rlen);
+        // (with segs_left == 1 the child returns [0,0,0] at main.js:221 whatever its direction: skip it)
+        if (a3 > 0.0 && segs_left > 1) r = unit(reflect(d, n), &rlen);
         // A5 refraction direction
         v3 f = mk(0, 0, 0); double flen = 0.0;
-        if (REFRACT && a4 > 0.0) {
+        if (REFRACT && a4 > 0.0 && segs_left > 1) {
           const double dn = dot(d, n);
           double cosi = -((dn < -1.0) ? -1.0 : min1(dn));              // -Math.max(-1, Math.min(1, dot))
           v3 nn = n; double eta;
@@ -261,15 +334,38 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             // Shadow scan (main.js:293-304).  `alive` is the per-lane "not yet fully blocked" flag; the
             // loop leaves early only when every lane of the wave is blocked (exec-mask loop exit).
             uint32_t tests = 0;
+#if !RT_STRICT
+            // walked from the light: origin = light k (uniform), direction = -sv, the hit point is at llen
+            const geom_kptr gl = (geom_kptr)L.geom_light + (size_t)k * N;
+#endif
             for (uint32_t j = 0; j < N; j++) {
               if ((int)j == hi) continue;                              // main.js:294 (q3)
-              bool in;
-              const double t = isect(geom[j], h, sv, eps, &in);
               tests++;
-              if (t < llen) {
-                const double oa4 = objs[j].albedo[4];
-                if (oa4 != 0.0) li = rt_div(li, oa4);                  // transparent occluder brightens (q2)
-                else { li = 0.0; break; }
+#if !RT_STRICT
+              const rt_geom g = {gl[j].ox, gl[j].oy, gl[j].oz, gl[j].r2};
+              const double tcl = -(sv.x * g.ox + sv.y * g.oy + sv.z * g.oz);   // along -sv, from the light
+              const double disc = __builtin_fma(tcl, tcl, -g.r2);
+              if (!(disc < 0.0)) {
+                RT_PIN();
+                const double thc = rt_sqrt_nn(disc);
+                const double t0 = llen - (tcl + thc), t1 = llen - (tcl - thc);   // back to distances from the hit point
+#else
+              const rt_geom g = {geom[j].ox, geom[j].oy, geom[j].oz, geom[j].r2};
+              const v3 Lv = mk(g.ox - h.x, g.oy - h.y, g.oz - h.z);
+              const double tca = dot(sv, Lv);
+              const double d2 = dot(Lv, Lv) - tca * tca;
+              if (!(d2 > g.r2)) {
+                RT_PIN();
+                const double thc = rt_sqrt_nn(g.r2 - d2);
+                const double t0 = tca - thc, t1 = tca + thc;
+#endif
+                const double t = (t0 < eps) ? t1 : t0;
+                if ((t < llen) && !(t < eps)) {
+                  RT_PIN();
+                  const double oa4 = objs[j].albedo[4];
+                  if (oa4 != 0.0) li = rt_div(li, oa4);                // transparent occluder brightens (q2)
+                  else { li = 0.0; break; }
+                }
               }
             }
             if (COUNT) cnt[2] += tests;
@@ -286,29 +382,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           specular = min1(specular) * a2;
         }
 
-        // A8 sampler
-        double col[3];
-        const int kind = m.sampler_kind;
-        if (kind == RT_SAMPLER_TEXTURE) {
-          const double u = RT_DIV_CONST(atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
-          const double v = RT_DIV_CONST(asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
-          const rt_texture_desc td = tex[m.texture];
-          const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
-          uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
-          xi = min(xi, td.width - 1u); yi = min(yi, td.height - 1u);   // memory safety only; u,v <= 1
-          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
-          col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
-          col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
-          if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
-        } else if (kind == RT_SAMPLER_CHECKER) {
-          const double u = RT_DIV_CONST(atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
-          const double v = RT_DIV_CONST(asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
-          const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
-          col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
-        } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
-
-        const bool go_r = (rlen != 0.0) && (segs_left > 1);
-        const bool go_f = REFRACT && (flen != 0.0) && (segs_left > 1);
+        const bool go_r = (rlen != 0.0);
+        const bool go_f = REFRACT && (flen != 0.0);
         if (!go_r && !go_f) {
           // children are absent or return [0,0,0] (segs == 0, main.js:221): x + 0*a == x
 #pragma unroll
