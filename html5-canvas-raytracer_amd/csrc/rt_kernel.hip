@@ -207,7 +207,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   const double eps = L.epsilon;
   frame<REFRACT> stack[RT_MAX_SEGS];
   int level = 0;
+#ifdef RT_ABLATE_BOUNCE
+  uint32_t segs_left = L.segs ? 1 : 0;
+#else
   uint32_t segs_left = L.segs;
+#endif
   double ret[3] = {0.0, 0.0, 0.0};
   [[maybe_unused]] bool primary = true;                 // the first node evaluated is the primary ray (origin = camera, uniform)
 
@@ -265,6 +269,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       const int hi = hcode >> 1;
       const bool inside = (hcode & 1) != 0;
       bool descend = false;
+#ifdef RT_ABLATE_SHADE
+      if (true) { ret[0] = ht; ret[1] = (double)hcode; ret[2] = 0.0; } else
+#endif
       if (hcode < 0) {                                // main.js:231
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
       } else {
@@ -280,7 +287,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         // A8 sampler (main.js:320).  Pure, so it is evaluated here, before the lighting, where few values
         // are live: the OCML atan2/asin bodies are the register-pressure peak of the kernel.
         double col[3];
+#ifdef RT_ABLATE_SAMPLER   /* timing experiments only (profiles/ab_build.sh); never defined in the product build */
+        const int kind = RT_SAMPLER_COLOR;
+#else
         const int kind = m.sampler_kind;
+#endif
         if (kind == RT_SAMPLER_TEXTURE) {
           const double u = RT_DIV_CONST(atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
           const double v = RT_DIV_CONST(asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
@@ -321,13 +332,23 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 
         // A7 lighting and shadows
         double diffuse = 0.0, specular = 0.0;
+#ifdef RT_ABLATE_LIGHT
+        if (false) {
+#else
         if (a1 > 0.0 || a2 > 0.0) {
+#endif
           double li = L.light_intensity;                               // shared across lights (q2)
           for (uint32_t k = 0; k < NL; k++) {
             double llen;
             const v3 sraw = mk(L.lights[k][0] - h.x, L.lights[k][1] - h.y, L.lights[k][2] - h.z);
             const double lmag = dot(sraw, sraw);
+#if RT_STRICT
             const v3 sv = unit(sraw, &llen);
+#else
+            const double inv_llen = rt_rsqrt_pos(lmag);               // lights never coincide with a surface point
+            llen = lmag * inv_llen;
+            const v3 sv = mk(sraw.x * inv_llen, sraw.y * inv_llen, sraw.z * inv_llen);
+#endif
             const double sdot = dot(sv, l);
             if (sdot <= 0.0) continue;                                 // surface faces away
             if (COUNT) cnt[1]++;
@@ -338,7 +359,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             // walked from the light: origin = light k (uniform), direction = -sv, the hit point is at llen
             const geom_kptr gl = (geom_kptr)L.geom_light + (size_t)k * N;
 #endif
+#ifdef RT_ABLATE_SHADOW
+            for (uint32_t j = 0; j < 0; j++) {
+#else
             for (uint32_t j = 0; j < N; j++) {
+#endif
               if ((int)j == hi) continue;                              // main.js:294 (q3)
               tests++;
 #if !RT_STRICT
@@ -370,11 +395,27 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             }
             if (COUNT) cnt[2] += tests;
             if (li == 0.0) continue;
-            diffuse += rt_div(li * sdot, lmag);
-            if (a2 > 0.0) {
+#if RT_STRICT
+            diffuse += li * sdot / lmag;                               // main.js:306
+#else
+            diffuse += (li * sdot) * (inv_llen * inv_llen);            // 1/lmag = (1/llen)^2, already at hand
+#endif
+#ifdef RT_ABLATE_SPEC
+            if (false) {
+#else
+            if (a2 > 0.0) {                                            // main.js:307-314
+#endif
+#if RT_STRICT
               double ql;
               const v3 q = unit(reflect(mk(-sv.x, -sv.y, -sv.z), l), &ql);
               const double spd = d.x * -q.x + d.y * -q.y + d.z * -q.z;
+#else
+              // reflect(-sv, l) = -sv + l*(2 sv.l): sv.l is sdot, and the mirror image of a unit vector in
+              // a unit normal is a unit vector, so the reference's re-normalisation moves it by an ulp at most
+              const double t2 = 2.0 * sdot;
+              const v3 q = mk(__builtin_fma(l.x, t2, -sv.x), __builtin_fma(l.y, t2, -sv.y), __builtin_fma(l.z, t2, -sv.z));
+              const double spd = -(d.x * q.x + d.y * q.y + d.z * q.z);
+#endif
               if (spd > 0.0) specular += rt_pow(spd, m.specular_exponent);
             }
           }

@@ -1,0 +1,46 @@
+'use strict';
+// render(width, height, scene) — the drop-in entry point for the reference's per-pixel path
+// (redraw()/spanish() + intersectWorld, /root/reference/main.js:180-201, :216-451), backed by the
+// MI355X HIP kernel through the N-API shim.  The returned Uint8ClampedArray has the layout of
+// ImageData.data (main.js:83, :195-198), so it drops in behind the canvas:
+//     ctx.putImageData(new ImageData(render(w, h, scene), w, h), 0, 0)
+// There is NO JavaScript rendering fallback here: if the addon or the GPU is missing, this throws.
+
+const path = require('path');
+const {flattenScene} = require('./flatten.js');
+const scene = require('./scene.js');
+const scenes = require('./scenes.js');
+
+let addon = null;
+function native() {
+  if (addon) return addon;
+  const p = path.join(__dirname, '..', 'napi', 'rt_napi.node');
+  try { addon = require(p); } catch (e) {
+    throw new Error('html5-canvas-raytracer_amd: native addon ' + p + ' is not built or cannot load (' + e.message +
+      '); run `python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback for render().');
+  }
+  return addon;
+}
+
+const FLAG_COUNT = 1, FLAG_STRICT_FP = 2;
+let inited = false;
+function init(maxDevices) { const n = native().init(maxDevices || 0); inited = true; return n; }
+function flagsOf(opts) { return ((opts && opts.count) ? FLAG_COUNT : 0) | ((opts && opts.strictFp) ? FLAG_STRICT_FP : 0); }
+
+// -> Uint8ClampedArray of length 4*width*height over a pinned host buffer; `.stats` carries timings
+function render(width, height, sceneObj, opts) {
+  if (!inited) init(opts && opts.maxDevices);
+  const r = native().render(flattenScene(sceneObj), width, height, flagsOf(opts));
+  r.data.stats = r.stats;
+  return r.data;
+}
+
+// Promise variant: the launch and the copy-out run off the event loop (napi_async_work)
+function renderAsync(width, height, sceneObj, opts) {
+  try { if (!inited) init(opts && opts.maxDevices); } catch (e) { return Promise.reject(e); }
+  return native().renderAsync(flattenScene(sceneObj), width, height, flagsOf(opts)).then((r) => { r.data.stats = r.stats; return r.data; });
+}
+
+function shutdown() { if (addon) addon.shutdown(); inited = false; }
+
+module.exports = Object.assign({render, renderAsync, init, shutdown, flattenScene, scenes, native}, scene);

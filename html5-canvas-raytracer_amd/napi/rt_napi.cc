@@ -1,0 +1,211 @@
+// rt_napi.cc — thin N-API shim between the Node.js host (js/index.js) and the C ABI of
+// include/rt_hip.h.  It does no rendering and no scene logic: the scene arrives already flattened
+// (js/flatten.js) as one ArrayBuffer, and the frame goes back as a Uint8ClampedArray over the
+// pinned host buffer the library filled — the object the reference's ImageData.data is
+// (main.js:83), so `context.putImageData(new ImageData(data, w, h), 0, 0)` works unchanged.
+//
+// Exports:  init(maxDevices) -> deviceCount      render(blob, w, h, flags) -> {data, width, height, stats}
+//           renderAsync(blob, w, h, flags) -> Promise of the same        shutdown()      abiVersion()
+// Every failure of the library becomes a thrown JS Error carrying rt_last_error().
+//
+// Build: g++ -shared -fPIC -I/usr/include/node rt_napi.cc -L../csrc -lrt_hip  (napi/Makefile; no node-gyp).
+
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/rt_hip.h"
+
+namespace {
+
+#define NAPI_TRY(call)                                                        \
+  do {                                                                        \
+    if ((call) != napi_ok) {                                                  \
+      napi_throw_error(env, nullptr, "N-API call failed: " #call);            \
+      return nullptr;                                                         \
+    }                                                                         \
+  } while (0)
+
+napi_value throw_rt(napi_env env, const char *what, int rc) {
+  std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + rt_last_error();
+  napi_throw_error(env, rc == RT_ERR_UNSUPPORTED ? "RT_ERR_UNSUPPORTED" : rc == RT_ERR_DEVICE ? "RT_ERR_DEVICE" : "RT_ERR", msg.c_str());
+  return nullptr;
+}
+
+void free_pinned(napi_env, void *data, void *) { rt_free_pinned(data); }
+
+struct args {
+  void *blob = nullptr;      // the scene blob; `owned` when it is our (re-aligned / off-thread) copy
+  bool owned = false;
+  size_t bytes = 0;
+  uint32_t w = 0, h = 0, flags = 0;
+  uint8_t *out = nullptr;
+  rt_stats st{};
+  int rc = 0;
+  std::string err;
+  napi_deferred deferred = nullptr;
+  napi_async_work work = nullptr;
+};
+
+bool parse(napi_env env, napi_callback_info info, args *a, bool copy_blob) {
+  size_t argc = 4;
+  napi_value argv[4];
+  if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 3) {
+    napi_throw_type_error(env, nullptr, "render(blob: ArrayBuffer, width, height[, flags])");
+    return false;
+  }
+  bool is_ab = false;
+  napi_is_arraybuffer(env, argv[0], &is_ab);
+  void *data = nullptr;
+  size_t len = 0;
+  if (is_ab) napi_get_arraybuffer_info(env, argv[0], &data, &len);
+  else {
+    bool is_ta = false;
+    napi_is_typedarray(env, argv[0], &is_ta);
+    if (!is_ta) { napi_throw_type_error(env, nullptr, "scene blob must be an ArrayBuffer or a typed array"); return false; }
+    napi_typedarray_type t; napi_value ab; size_t off;
+    napi_get_typedarray_info(env, argv[0], &t, &len, &data, &ab, &off);
+    if (t != napi_uint8_array && t != napi_uint8_clamped_array) { napi_throw_type_error(env, nullptr, "typed-array blob must be Uint8Array"); return false; }
+  }
+  if (napi_get_value_uint32(env, argv[1], &a->w) != napi_ok || napi_get_value_uint32(env, argv[2], &a->h) != napi_ok || a->w == 0 || a->h == 0) {
+    napi_throw_type_error(env, nullptr, "width and height must be positive integers");
+    return false;
+  }
+  if (argc >= 4) napi_get_value_uint32(env, argv[3], &a->flags);
+  a->bytes = len;
+  if (copy_blob || ((uintptr_t)data & 7u) != 0) {       // the library wants 8-byte alignment
+    a->blob = aligned_alloc(16, (len + 15) & ~(size_t)15);
+    if (!a->blob) { napi_throw_error(env, nullptr, "out of memory"); return false; }
+    memcpy(a->blob, data, len);
+    a->owned = true;
+  } else a->blob = data;
+  return true;
+}
+
+napi_value make_result(napi_env env, args *a) {
+  const size_t n = (size_t)a->w * a->h * 4u;
+  napi_value ab, ta, res, stats, v;
+  NAPI_TRY(napi_create_external_arraybuffer(env, a->out, n, free_pinned, nullptr, &ab));
+  a->out = nullptr;    // owned by the ArrayBuffer's finalizer from here on
+  NAPI_TRY(napi_create_typedarray(env, napi_uint8_clamped_array, n, ab, 0, &ta));
+  NAPI_TRY(napi_create_object(env, &res));
+  NAPI_TRY(napi_create_object(env, &stats));
+  napi_set_named_property(env, res, "data", ta);
+  napi_create_uint32(env, a->w, &v); napi_set_named_property(env, res, "width", v);
+  napi_create_uint32(env, a->h, &v); napi_set_named_property(env, res, "height", v);
+  napi_create_double(env, a->st.kernel_ms, &v); napi_set_named_property(env, stats, "kernel_ms", v);
+  napi_create_double(env, a->st.total_ms, &v); napi_set_named_property(env, stats, "total_ms", v);
+  napi_create_double(env, (double)a->st.pixels, &v); napi_set_named_property(env, stats, "pixels", v);
+  napi_create_double(env, (double)a->st.rays, &v); napi_set_named_property(env, stats, "rays", v);
+  napi_create_double(env, (double)a->st.shadow_rays, &v); napi_set_named_property(env, stats, "shadow_rays", v);
+  napi_create_double(env, (double)a->st.sphere_tests, &v); napi_set_named_property(env, stats, "sphere_tests", v);
+  napi_set_named_property(env, res, "stats", stats);
+  return res;
+}
+
+napi_value Init(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  uint32_t maxdev = 0;
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  if (argc >= 1) napi_get_value_uint32(env, argv[0], &maxdev);
+  int rc = rt_init((int)maxdev);
+  if (rc != RT_OK) return throw_rt(env, "rt_init", rc);
+  napi_value v;
+  napi_create_int32(env, rt_device_count(), &v);
+  return v;
+}
+
+napi_value Render(napi_env env, napi_callback_info info) {
+  args a;
+  if (!parse(env, info, &a, false)) return nullptr;
+  napi_value res = nullptr;
+  a.out = (uint8_t *)rt_alloc_pinned((size_t)a.w * a.h * 4u);
+  if (!a.out) res = throw_rt(env, "rt_alloc_pinned", RT_ERR_NOMEM);
+  else {
+    a.rc = rt_render(a.blob, a.bytes, a.w, a.h, a.out, a.flags, &a.st);
+    if (a.rc != RT_OK) { rt_free_pinned(a.out); a.out = nullptr; res = throw_rt(env, "rt_render", a.rc); }
+    else res = make_result(env, &a);
+  }
+  if (a.owned) free(a.blob);
+  return res;
+}
+
+void exec_async(napi_env, void *p) {
+  args *a = (args *)p;
+  a->out = (uint8_t *)rt_alloc_pinned((size_t)a->w * a->h * 4u);
+  if (!a->out) { a->rc = RT_ERR_NOMEM; a->err = rt_last_error(); return; }
+  a->rc = rt_render(a->blob, a->bytes, a->w, a->h, a->out, a->flags, &a->st);
+  if (a->rc != RT_OK) { a->err = rt_last_error(); rt_free_pinned(a->out); a->out = nullptr; }   // rt_last_error is per thread: read it here
+}
+
+void done_async(napi_env env, napi_status, void *p) {
+  args *a = (args *)p;
+  if (a->rc == RT_OK) {
+    napi_value res = make_result(env, a);
+    if (res) napi_resolve_deferred(env, a->deferred, res);
+  } else {
+    napi_value msg, err;
+    std::string m = "rt_render failed (" + std::to_string(a->rc) + "): " + a->err;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &err);
+    napi_reject_deferred(env, a->deferred, err);
+  }
+  napi_delete_async_work(env, a->work);
+  if (a->owned) free(a->blob);
+  delete a;
+}
+
+napi_value RenderAsync(napi_env env, napi_callback_info info) {
+  args *a = new args();
+  if (!parse(env, info, a, true)) { if (a->owned) free(a->blob); delete a; return nullptr; }
+  napi_value promise, name;
+  NAPI_TRY(napi_create_promise(env, &a->deferred, &promise));
+  napi_create_string_utf8(env, "rt_render", NAPI_AUTO_LENGTH, &name);
+  NAPI_TRY(napi_create_async_work(env, nullptr, name, exec_async, done_async, a, &a->work));
+  NAPI_TRY(napi_queue_async_work(env, a->work));
+  return promise;
+}
+
+napi_value Shutdown(napi_env, napi_callback_info) { rt_shutdown(); return nullptr; }
+
+napi_value AbiVersion(napi_env env, napi_callback_info) {
+  napi_value v;
+  napi_create_uint32(env, rt_abi_version(), &v);
+  return v;
+}
+
+napi_value Validate(napi_env env, napi_callback_info info) {
+  args a;
+  size_t argc = 1; napi_value argv[1]; void *data = nullptr; size_t len = 0; bool is_ab = false;
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  if (argc < 1 || napi_is_arraybuffer(env, argv[0], &is_ab) != napi_ok || !is_ab) { napi_throw_type_error(env, nullptr, "validate(blob: ArrayBuffer)"); return nullptr; }
+  napi_get_arraybuffer_info(env, argv[0], &data, &len);
+  void *copy = aligned_alloc(16, (len + 15) & ~(size_t)15);
+  memcpy(copy, data, len);
+  const int rc = rt_scene_validate(copy, len);
+  free(copy);
+  if (rc != RT_OK) return throw_rt(env, "rt_scene_validate", rc);
+  napi_value v; napi_get_boolean(env, true, &v);
+  return v;
+}
+
+napi_value Module(napi_env env, napi_value exports) {
+  const napi_property_descriptor props[] = {
+      {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"renderAsync", nullptr, RenderAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"validate", nullptr, Validate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"shutdown", nullptr, Shutdown, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(rt_napi, Module)

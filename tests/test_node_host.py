@@ -1,0 +1,48 @@
+"""The Node.js host: render(width,height,scene) -> N-API shim -> C ABI -> HIP kernel."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import oracle_util as ou
+
+ROOT = ou.ROOT
+PKG = os.path.join(ROOT, "html5-canvas-raytracer_amd")
+needs_node = pytest.mark.skipif(ou.node_path() is None, reason="node not installed")
+
+
+@needs_node
+def test_addon_loads_and_fails_loudly_without_gpu(built):
+    """CPU-side: the addon exports its surface, validates blobs, and render() throws (no JS fallback)."""
+    assert os.path.exists(os.path.join(PKG, "napi", "rt_napi.node")), "N-API shim was not built"
+    js = """
+const rt = require('%s/js/index.js'); const F = require('%s/js/flatten.js'); const fs = require('fs');
+const n = rt.native();
+const sc = F.sceneFromJSON(fs.readFileSync('%s/scenes/cfg1.json', 'utf8'), '%s/scenes');
+const out = {exports: Object.keys(n).sort(), abi: n.abiVersion(), valid: n.validate(rt.flattenScene(sc)), err: ''};
+try { rt.render(16, 16, sc); out.err = 'rendered'; } catch (e) { out.err = e.message; }
+console.log(JSON.stringify(out));
+""" % (PKG, PKG, PKG, PKG)
+    out = json.loads(subprocess.check_output([ou.node_path(), "-e", js], text=True))
+    assert out["exports"] == ["abiVersion", "init", "render", "renderAsync", "shutdown", "validate"]
+    assert out["abi"] == 1 and out["valid"] is True
+    import torch
+    if not torch.cuda.is_available():
+        assert "no HIP device" in out["err"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_render_matches_reference_frames(built):
+    r = subprocess.run([ou.node_path(), os.path.join(ROOT, "tests", "js_render_check.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["devices"] >= 1
+    for name, f in out["frames"].items():
+        assert f["type"] == "[object Uint8ClampedArray]", name
+        assert f["diff"] <= 1, (name, f)
+    assert out["constructed"] <= 1 and out["async"] <= 1
+    assert out["counted"]["pixels"] == 240 * 135 and out["counted"]["rays"] > out["counted"]["pixels"]
+    assert "sampler" in out["unsupported"]
