@@ -195,12 +195,12 @@ napi_value Validate(napi_env env, napi_callback_info info) {
 
 napi_value Module(napi_env env, napi_value exports) {
   const napi_property_descriptor props[] = {
-      {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"renderAsync", nullptr, RenderAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"validate", nullptr, Validate, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"shutdown", nullptr, Shutdown, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"renderAsync", nullptr, RenderAsync, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"validate", nullptr, Validate, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"shutdown", nullptr, Shutdown, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;
