@@ -92,11 +92,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_REHEARSE=1: rehearsal of the N>1 control flow on a ONE-GPU box — every rank shares GPU 0 and
+    # the gather goes over gloo through host memory.  Never a measurement (the JSON says so).
+    rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, h = frame_size_for(world)
     if args.width and args.height:
@@ -104,12 +111,12 @@ def main():
     scene = rt_host.load_scene(args.scene)
     ss = scene.get("supersample", 1)
     lib = rt_host.load_library()
-    renderer = rt_host.Renderer(scene, local_rank, lib)          # scene resident in HBM from here on
+    renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
     flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
 
-    n_tiles = (h + TILE_ROWS - 1) // TILE_ROWS
-    per_rank = (n_tiles + world - 1) // world
-    band_rows = per_rank * TILE_ROWS
+    import shard
+    plan = shard.TilePlan(w, h, TILE_ROWS, world)
+    per_rank, band_rows = plan.tiles_per_rank, plan.band_rows
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
     # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
     tstream = torch.cuda.Stream(device=dev)
@@ -123,7 +130,8 @@ def main():
         bands = [torch.empty((band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
         frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
         gathered = [torch.empty((world, band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if rank == 0 else None
-    my_tiles = rt_host.RtTiles(TILE_ROWS, rank, world, per_rank)
+    my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
+    host_gathered = torch.empty((world, band_rows, w, 4), dtype=torch.uint8) if (rehearse and rank == 0) else None
     whole = rt_host.RtTiles(h, 0, 1, 1)
 
     pending = []      # (work, slot) of gathers in flight; at most 2
@@ -132,10 +140,9 @@ def main():
         work, slot = slot_work
         work.wait()                                              # current stream waits for the gather
         if rank == 0:
-            rc = lib.rt_deinterleave_device(local_rank, gathered[slot].data_ptr(), frame.data_ptr(), w, h, TILE_ROWS, world,
-                                            band_rows * w * 4, stream)
-            if rc != 0:
-                raise rt_host.RtError(lib.rt_last_error().decode())
+            if rehearse:
+                gathered[slot].copy_(host_gathered)
+            shard.deinterleave(plan, gathered[slot], frame, lib=lib, device_index=dev_index, stream=stream)
 
     def step(k):
         if world == 1:
@@ -145,7 +152,10 @@ def main():
         if len(pending) == 2:                                    # the gather that last used this slot
             finish(pending.pop(0))
         renderer.render_tiles(w, h, bands[slot].data_ptr(), my_tiles, stream=stream, flags=flags)
-        work = dist.gather(bands[slot], list(gathered[slot].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+        if rehearse:
+            work = shard.gather_bands(bands[slot].cpu(), host_gathered if rank == 0 else None, dst=0, async_op=True)
+        else:
+            work = shard.gather_bands(bands[slot], gathered[slot] if rank == 0 else None, dst=0, async_op=True)
         pending.append((work, slot))                             # overlaps with the next step's render
 
     def drain():
@@ -184,8 +194,7 @@ def main():
         b.record()
     torch.cuda.synchronize()
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-    launch_pixels = sum(max(0, min(h, (rank + i * world + 1) * TILE_ROWS) - (rank + i * world) * TILE_ROWS) for i in range(per_rank)) * w \
-        if world > 1 else w * h
+    launch_pixels = plan.pixels_of(rank) if world > 1 else w * h
 
     # one more (untimed) frame on every rank, checked on rank 0 against the reference's rows
     step(0)
@@ -221,7 +230,8 @@ def main():
             "config": {"workload": "%s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; %s" % (
                 args.scene, len(scene["objects"]), len(scene["lights"]), scene["segs"], ss, w, h,
                 "one launch per frame" if world == 1 else "interleaved %d-row tiles over %d ranks + RCCL gather to rank 0 + de-interleave" % (TILE_ROWS, world)),
-                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "pixels_per_gpu": pixels // world},
+                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "pixels_per_gpu": pixels // world,
+                **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {})},
             "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
             "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
             "max_lsb_vs_reference_rows": max_lsb,

@@ -1,0 +1,75 @@
+"""Row-tile sharding of one frame over the ranks of a node, and its reassembly on rank 0.
+
+The reference walks the frame one scanline per macrotask (spanish(y), main.js:183-201); every pixel
+is independent, so the frame shards with no exchange during rendering.  Here the frame is cut into
+tiles of `tile_rows` rows dealt round-robin to the ranks (sky rows are several times cheaper than
+floor rows, so contiguous bands would be badly balanced); each rank renders its tiles contiguously
+into a band, ONE gather (RCCL when the tensors are on GPUs, gloo in the CPU tests) brings the bands to
+rank 0, and one de-interleave pass puts the rows in frame order.
+
+Used by bench.py (GPU, backend "nccl") and by tests/test_shard_gloo.py (CPU, backend "gloo",
+world_size 2) — the same code path, only the band producer differs.
+"""
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class TilePlan:
+    w: int
+    h: int
+    tile_rows: int
+    world: int
+
+    @property
+    def n_tiles(self):
+        return (self.h + self.tile_rows - 1) // self.tile_rows
+
+    @property
+    def tiles_per_rank(self):
+        return (self.n_tiles + self.world - 1) // self.world
+
+    @property
+    def band_rows(self):
+        return self.tiles_per_rank * self.tile_rows
+
+    @property
+    def band_bytes(self):
+        return self.band_rows * self.w * 4
+
+    def rt_tiles(self, rank):
+        """(tile_rows, tile_first, tile_stride, n_tiles) for rt_render_tiles_device on `rank`."""
+        return (self.tile_rows, rank, self.world, self.tiles_per_rank)
+
+    def rows_of(self, rank):
+        """Frame rows rank `rank` owns, in band order (rows past the frame's end are left out)."""
+        rows = []
+        for i in range(self.tiles_per_rank):
+            t = rank + i * self.world
+            rows.extend(range(t * self.tile_rows, min(self.h, (t + 1) * self.tile_rows)))
+        return rows
+
+    def pixels_of(self, rank):
+        return len(self.rows_of(rank)) * self.w
+
+
+def gather_bands(band, gathered, dst=0, async_op=False):
+    """One gather of every rank's band ([band_rows, w, 4] uint8) into `gathered` ([world, band_rows, w, 4],
+    rank `dst` only; None elsewhere).  Returns the work handle when async_op."""
+    import torch.distributed as dist
+    recv = list(gathered.unbind(0)) if dist.get_rank() == dst else None
+    return dist.gather(band, recv, dst=dst, async_op=async_op)
+
+
+def deinterleave(plan, gathered, frame, lib=None, device_index=0, stream=0):
+    """gathered [world, band_rows, w, 4] -> frame [h, w, 4] in row order.
+    GPU tensors: the library's HBM->HBM kernel (rt_deinterleave_device) on `stream`.
+    CPU tensors (tests): the same permutation expressed with torch views."""
+    if gathered.is_cuda:
+        rc = lib.rt_deinterleave_device(device_index, gathered.data_ptr(), frame.data_ptr(), plan.w, plan.h, plan.tile_rows, plan.world,
+                                        plan.band_bytes, stream)
+        if rc != 0:
+            raise RuntimeError("rt_deinterleave_device: " + lib.rt_last_error().decode())
+        return frame
+    v = gathered.view(plan.world, plan.tiles_per_rank, plan.tile_rows, plan.w, 4).permute(1, 0, 2, 3, 4)
+    frame.copy_(v.reshape(-1, plan.w, 4)[:plan.h])
+    return frame

@@ -84,6 +84,8 @@ frame('h8_240x135', 'h8', 240, 135, null);
 frame('h8_d8_160x90', 'h8_d8', 160, 90, null);
 frame('h8_3840x2160_rows', 'h8', 3840, 2160, [0, 540, 900, 1000, 1080, 1200, 1400, 1700, 2159], 'BASELINE configs[2], sampled rows');
 frame('h8_7680x4320_rows', 'h8', 7680, 4320, [1, 2000, 2400, 3000], 'BASELINE configs[3], sampled rows');
+frame('h8_5440x3056_rows', 'h8', 5440, 3056, [3, 1500, 1700, 2200], 'bench.py frame at 2 GPUs (one 4K frame of pixels per GPU), sampled rows');
+frame('h8_10848x6112_rows', 'h8', 10848, 6112, [5, 3000, 3400, 4400], 'bench.py frame at 8 GPUs, sampled rows');
 frame('lcg64_ss2_128x128', 'lcg64', 128, 128, null, 'cfg5 scene: reference at 256x256 then (a+b+c+d+2)>>2');
 frame('lcg64_ss1_192x192', 'lcg64_ss1', 192, 192, null);
 // hashes of larger frames

@@ -1,0 +1,53 @@
+"""world_size-N CPU worker for tests/test_shard_gloo.py (backend gloo).
+
+Each rank produces its band of interleaved row tiles (here with the ORACLE's C restatement, because
+there is no GPU in the build container — the sharding/gather/de-interleave code under test is
+html5-canvas-raytracer_amd/shard.py, the same code bench.py runs over RCCL), the bands are gathered to
+rank 0 and de-interleaved, and rank 0 compares the frame with the whole frame rendered at once.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "html5-canvas-raytracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_util as ou  # noqa: E402
+import rt_host  # noqa: E402
+import shard  # noqa: E402
+
+
+def main():
+    scene, w, h, tile_rows = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    plan = shard.TilePlan(w, h, tile_rows, world)
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    band = torch.zeros((plan.band_rows, w, 4), dtype=torch.uint8)
+    rows = plan.rows_of(rank)
+    if rows:
+        data = np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8).reshape(len(rows), w, 4)
+        band[:len(rows)] = torch.from_numpy(data.copy())
+    gathered = torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8) if rank == 0 else None
+    work = shard.gather_bands(band, gathered, dst=0, async_op=True)
+    work.wait()
+    ok = 1
+    if rank == 0:
+        frame = torch.empty((h, w, 4), dtype=torch.uint8)
+        shard.deinterleave(plan, gathered, frame)
+        whole = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h, w, 4)
+        ok = int(np.array_equal(frame.numpy(), whole))
+        assert sum(plan.pixels_of(r) for r in range(world)) == w * h
+        print("DIST_RESULT world=%d identical=%d" % (world, ok), flush=True)
+    t = torch.tensor([ok])
+    dist.broadcast(t, src=0)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(t.item()) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
