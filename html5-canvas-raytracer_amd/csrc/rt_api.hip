@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -19,8 +20,8 @@
 
 #include "rt_device.h"
 
-extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, unsigned, hipStream_t);
-extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, unsigned, hipStream_t);
+extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, hipStream_t);
+extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, hipStream_t);
 
 // ------------------------------------------------------------------------------------ state
 namespace {
@@ -83,6 +84,7 @@ struct rt_scene_dev {
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
   unsigned lds_bytes;
   double lights[RT_MAX_LIGHTS][3];   // host copy: lights travel in the kernarg segment
+  uint32_t enclosing;            // sphere that strictly contains everything else (a skybox), or ~0u
 };
 
 // ------------------------------------------------------------------------------------ lifetime
@@ -165,6 +167,24 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   rt_texture_desc descs[RT_MAX_TEXTURES];
   memset(descs, 0, sizeof descs);
   if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
+  // Enclosing sphere: every other sphere, every light and the camera strictly inside it, with a margin far
+  // above rounding.  Such a sphere never shadows anything and is the closest hit only of rays that hit
+  // nothing else, which lets the product kernel take it out of the per-ray loops (exact, not approximate).
+  s->enclosing = ~0u;
+  for (uint32_t e = 0; e < hd->n_objects && s->enclosing == ~0u; e++) {
+    const double re = sqrt(ob[e].r2), lim = re * (1.0 - 1e-6);
+    auto dist_to = [&](const double q[3]) { const double x = q[0] - ob[e].origin[0], y = q[1] - ob[e].origin[1], z = q[2] - ob[e].origin[2]; return sqrt(x * x + y * y + z * z); };
+    bool ok = re > 0.0 && dist_to(hd->cam_origin) < lim;
+    for (uint32_t k = 0; k < hd->n_lights && ok; k++) ok = dist_to(s->lights[k]) < lim;
+    for (uint32_t j = 0; j < hd->n_objects && ok; j++) if (j != e) ok = dist_to(ob[j].origin) + sqrt(ob[j].r2) < lim;
+    if (ok && hd->n_objects > 1) s->enclosing = e;
+  }
+  // device copy of the blob: the `reserved` slot of each sphere record carries 1/r for the product kernel
+  std::vector<uint8_t> patched((const uint8_t *)blob, (const uint8_t *)blob + bytes);
+  {
+    rt_sphere *pob = (rt_sphere *)(patched.data() + hd->objects_offset);
+    for (uint32_t i = 0; i < hd->n_objects; i++) pob[i].reserved = 1.0 / sqrt(pob[i].r2);
+  }
   // geometry tables: [0,N) plain, [N,2N) anchored at the camera, [2N, 2N + NL*N) anchored at each light
   const uint32_t NO = hd->n_objects;
   std::vector<rt_geom> geom((size_t)NO * (2 + hd->n_lights));
@@ -181,7 +201,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
   if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(s->d_blob, blob, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->d_blob, patched.data(), bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_texdesc, descs, sizeof descs, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (s->d_blob) (void)hipFree(s->d_blob);
@@ -242,16 +262,17 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
   memcpy(L.lights, s->lights, sizeof L.lights);
 
-  const uint32_t local_rows = tiles->n_tiles * tiles->tile_rows;
-  const uint32_t rows_per_wg = ss2 ? 2u : RT_TILE_H;
-  const uint64_t blocks = (uint64_t)L.tiles_x * ((local_rows + rows_per_wg - 1) / rows_per_wg);
-  if (blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "grid too large");
+  if (tiles->n_tiles > 65535u) return fail(RT_ERR_INVALID, "n_tiles %u > 65535 (grid z)", tiles->n_tiles);
+  for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
+  L.enclosing = s->enclosing;
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
-  const int err = ((flags & RT_FLAG_STRICT_FP) ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, (unsigned)blocks, s->lds_bytes, stream);
+  // RT_LDS_PAD (bytes): occupancy experiments only — extra dynamic LDS per workgroup caps the workgroups per CU
+  static const unsigned lds_pad = getenv("RT_LDS_PAD") ? (unsigned)atoi(getenv("RT_LDS_PAD")) : 0u;
+  const int err = ((flags & RT_FLAG_STRICT_FP) ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, s->lds_bytes + lds_pad, stream);
   if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
   if (stats) {
     HIP_TRY(hipEventRecord(ev1, stream));

@@ -30,6 +30,7 @@ struct rt_launch {
   unsigned long long *counters;      // rays, shadow rays, sphere tests (COUNT variant only)
   // camera + projection (main.js:85-105), projection constants computed on the host in binary64
   double cam_origin[3], cam_axis_x[3], cam_axis_y[3], cam_axis_z[3];
+  double cam_axis_sum[3];            // axisX[k] + axisY[k] + axisZ[k] (product kernel's ray generation)
   double proj_w, proj_h, proj_d;     // of the SAMPLE grid (2w x 2h when supersampling)
   double epsilon, light_intensity, miss_color[3];
   double lights[RT_MAX_LIGHTS][3];
@@ -37,6 +38,7 @@ struct rt_launch {
   uint32_t w, h;                     // output frame size in pixels
   uint32_t tile_rows, tile_first, tile_stride, n_tiles;   // rt_tiles
   uint32_t tiles_x;                  // workgroup tiles per row of the frame
+  uint32_t enclosing;                // index of a sphere that strictly contains every other sphere, light and the camera; ~0u if none
 };
 
 #endif

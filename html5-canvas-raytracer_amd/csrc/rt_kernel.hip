@@ -122,6 +122,9 @@ __device__ __forceinline__ double rt_div_const(double a, double c, double rc) {
   const double q = a * rc;
   return __builtin_fma(__builtin_fma(-q, c, a), rc, q);
 }
+// Non-integer exponents (none in the reference scene) take OCML's pow out of line, so that its ~40
+// temporaries are not part of the register budget of the loop every pixel runs.
+__device__ __attribute__((noinline)) double rt_pow_generic(double x, double e) { return pow(x, e); }
 // x > 0.  Integer exponents (every specular_exponent of the reference scene, main.js:108-123) by
 // square-and-multiply: <= 2*log2(e) multiplies instead of OCML's ~150-instruction pow.
 __device__ __forceinline__ double rt_pow(double x, double e) {
@@ -132,7 +135,7 @@ __device__ __forceinline__ double rt_pow(double x, double e) {
     while (k) { if (k & 1u) r *= b; b *= b; k >>= 1; }
     return r;
   }
-  return pow(x, e);
+  return rt_pow_generic(x, e);
 }
 // main.js:62-66 — v * (1/len), len = sqrt(v.v); the zero vector is returned unchanged
 __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
@@ -163,10 +166,9 @@ __device__ __forceinline__ int to_int32_bit0(double x) {
 
 // Uint8ClampedArray store of 255*c (main.js:195-197): NaN -> 0, clamp, round half to even
 __device__ __forceinline__ uint32_t to_byte(double c) {
-  const double v = 255.0 * c;
-  if (!(v > 0.0)) return 0u;
-  if (v >= 255.0) return 255u;
-  return (uint32_t)rint(v);
+  // fmax(NaN, 0) = 0 and the clamp precede the conversion, so v_cvt_u32_f64 never sees an out-of-range
+  // value; v_rndne_f64 rounds half to even.
+  return (uint32_t)__builtin_rint(__builtin_fmin(__builtin_fmax(255.0 * c, 0.0), 255.0));
 }
 
 // main.js:420-439, as a "candidate root" test.  With thc >= 0 (or NaN) the reference's two-armed
@@ -205,6 +207,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
   const double eps = L.epsilon;
+  [[maybe_unused]] const uint32_t enc = L.enclosing;   // index of the enclosing sphere, or ~0u
   frame<REFRACT> stack[RT_MAX_SEGS];
   int level = 0;
 #ifdef RT_ABLATE_BOUNCE
@@ -229,6 +232,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const geom_kptr ga = (geom_kptr)L.geom_cam;
 #pragma unroll 2
         for (uint32_t i = 0; i < N; i++) {
+          if (i == enc) continue;
           const rt_geom g = {ga[i].ox, ga[i].oy, ga[i].oz, ga[i].r2};
           const double tca = d.x * g.ox + d.y * g.oy + d.z * g.oz;
           const double disc = __builtin_fma(tca, tca, -g.r2);        // r2 - d2
@@ -248,6 +252,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       {
 #pragma unroll 2
         for (uint32_t i = 0; i < N; i++) {
+#if !RT_STRICT
+          if (i == enc) continue;
+#endif
           const rt_geom g = {geom[i].ox, geom[i].oy, geom[i].oz, geom[i].r2};
           const v3 Lv = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
           const double tca = dot(d, Lv);
@@ -264,6 +271,24 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           }
         }
       }
+#if !RT_STRICT
+      // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) can
+      // only be the closest hit of a ray that hits nothing else, and such a ray starts inside it: one
+      // root behind, one ahead.  Only the lanes still without a hit evaluate it.
+      if (enc < N && hcode < 0) {
+        const rt_geom g = {geom[enc].ox, geom[enc].oy, geom[enc].oz, geom[enc].r2};
+        const v3 Lv = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
+        const double tca = dot(d, Lv);
+        const double d2 = dot(Lv, Lv) - tca * tca;
+        if (!(d2 > g.r2)) {
+          const double thc = rt_sqrt_nn(g.r2 - d2);
+          const double t0 = tca - thc, t1 = tca + thc;
+          const bool in = (t0 < eps);
+          const double t = in ? t1 : t0;
+          if (!(t < eps) && (t < RT_INF)) { ht = t; hcode = (int)(2u * enc) + (in ? 1 : 0); }
+        }
+      }
+#endif
       primary = false;
       if (COUNT) cnt[2] += N;
       const int hi = hcode >> 1;
@@ -278,8 +303,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const rt_sphere &m = mtl[hi];                 // LDS, per-lane index
         // A2 ext part for the closest hit only (main.js:440-447; pure, so deferring it is exact)
         const v3 h = mk(p.x + d.x * ht, p.y + d.y * ht, p.z + d.z * ht);
+#if RT_STRICT
         double nlen;
         const v3 n = unit(mk(h.x - m.origin[0], h.y - m.origin[1], h.z - m.origin[2]), &nlen);
+#else
+        // the hit point lies on the sphere, so |h - o| is r up to the rounding of h: scale by the stored 1/r
+        const double inv_r = m.reserved;
+        const v3 n = mk((h.x - m.origin[0]) * inv_r, (h.y - m.origin[1]) * inv_r, (h.z - m.origin[2]) * inv_r);
+#endif
         const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
         const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
         const double a4 = REFRACT ? m.albedo[4] : 0.0;
@@ -365,7 +396,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             for (uint32_t j = 0; j < N; j++) {
 #endif
               if ((int)j == hi) continue;                              // main.js:294 (q3)
-              tests++;
+              tests++;                                                 // counts the reference's intersectSphere calls
+#if !RT_STRICT
+              if (j == enc) continue;                                  // never between a surface point and a light
+#endif
 #if !RT_STRICT
               const rt_geom g = {gl[j].ox, gl[j].oy, gl[j].oz, gl[j].r2};
               const double tcl = -(sv.x * g.ox + sv.y * g.oy + sv.z * g.oz);   // along -sv, from the light
@@ -493,24 +527,30 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  const uint32_t tile_x = blockIdx.x % L.tiles_x, tile_y = blockIdx.x / L.tiles_x;
-  uint32_t px, lrow, sub = 0;
-  if (!SS2) { px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); lrow = tile_y * RT_TILE_H + (lane >> 3); }
-  else { const uint32_t q = lane >> 2; sub = lane & 3u; px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); lrow = tile_y * 2u + (q >> 3); }
-  const uint32_t ti = lrow / L.tile_rows;
-  const uint32_t frow = (L.tile_first + ti * L.tile_stride) * L.tile_rows + (lrow - ti * L.tile_rows);
-  const bool valid = (px < L.w) && (ti < L.n_tiles) && (frow < L.h);
+  // grid = (tiles across the frame, row blocks per tile, tiles of this call): no integer division anywhere
+  const uint32_t tile_x = blockIdx.x, row_block = blockIdx.y, tile_i = blockIdx.z;
+  uint32_t px, trow, sub = 0;                          // trow = row inside tile `tile_i`
+  if (!SS2) { px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); trow = row_block * RT_TILE_H + (lane >> 3); }
+  else { const uint32_t q = lane >> 2; sub = lane & 3u; px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); trow = row_block * 2u + (q >> 3); }
+  const uint32_t frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + trow;   // frame row
+  const uint32_t lrow = tile_i * L.tile_rows + trow;                                    // row in this call's output band
+  const bool valid = (px < L.w) && (trow < L.tile_rows) && (frow < L.h);
   const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px;
   const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
 
   // ---- A1 primary ray (main.js:186-193); dist is indexed by component k, not by axis (q1) ----
   const double d0 = ((double)sx - L.proj_w) + 0.5, d1 = (L.proj_h - (double)sy) - 0.5, d2 = L.proj_d;
   const v3 o = mk(L.cam_origin[0], L.cam_origin[1], L.cam_origin[2]);
+  double rl;
+#if RT_STRICT
   const v3 target = mk(o.x + L.cam_axis_x[0] * d0 + L.cam_axis_y[0] * d0 + L.cam_axis_z[0] * d0,
                        o.y + L.cam_axis_x[1] * d1 + L.cam_axis_y[1] * d1 + L.cam_axis_z[1] * d1,
                        o.z + L.cam_axis_x[2] * d2 + L.cam_axis_y[2] * d2 + L.cam_axis_z[2] * d2);
-  double rl;
   const v3 ray = unit(mk(target.x - o.x, target.y - o.y, target.z - o.z), &rl);
+#else
+  // target[k] - origin[k] = (axisX[k] + axisY[k] + axisZ[k]) * dist[k]; the sums come from the host
+  const v3 ray = unit(mk(L.cam_axis_sum[0] * d0, L.cam_axis_sum[1] * d1, L.cam_axis_sum[2] * d2), &rl);
+#endif
 
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
@@ -542,9 +582,10 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 }  // namespace
 
 // Host-side launcher for this translation unit's kernels.  Returns a hipError_t as int.
-extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned grid_blocks, unsigned lds_bytes,
-                              hipStream_t stream) {
-  const dim3 grid(grid_blocks), block(RT_WG_THREADS);
+extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned lds_bytes, hipStream_t stream) {
+  // x: 32-pixel tiles across the frame; y: row blocks (8 rows, or 2 when supersampling) per tile; z: tiles
+  const unsigned rows_per_wg = ss2 ? 2u : RT_TILE_H;
+  const dim3 grid(L->tiles_x, (L->tile_rows + rows_per_wg - 1) / rows_per_wg, L->n_tiles), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S) hipLaunchKernelGGL((rt_trace<R, C, S>), grid, block, lds_bytes, stream, *L)
   if (!count) {
     if (!refract) { if (!ss2) RT_CASE(false, false, false); else RT_CASE(false, false, true); }

@@ -231,3 +231,27 @@ def test_strict_and_fma_kernels_agree_within_1_lsb_at_4k(lib):
     b = gpu_frame(lib, blob, w, h, STRICT)
     worst, frac = ou.max_lsb(a, b)
     assert worst <= 1 and frac < 0.01
+
+
+@pytest.mark.parametrize("variant", ["light_outside", "reflective_sky", "camera_outside", "nested_skies", "sky_not_last"])
+def test_enclosing_sphere_shortcut_is_exact(lib, variant):
+    """The product kernel takes a sphere that strictly contains everything (a skybox) out of its per-ray
+    loops.  Scenes where the premise holds, barely fails, or holds for a shaded / reflective sphere."""
+    s = rt_host.load_scene("h8")
+    sky = next(o for o in s["objects"] if o["r2"] == 25000000.0)
+    if variant == "light_outside":
+        s["lights"] = [[5.0, 10.0, 5.0], [0.0, 6000.0, 0.0]]            # premise fails: no shortcut
+    elif variant == "reflective_sky":
+        sky["mtl"].update(color=[0.2, 0.3, 0.9], albedo=[0.3, 0.6, 0.4, 0.5, 0.0], specular_exponent=20)
+        s["segs"] = 4
+    elif variant == "camera_outside":
+        sky["r2"] = 36.0                                                # a 6-unit ball around the origin: camera at z=10 is outside
+        sky["mtl"].update(color=[0.1, 0.5, 0.1], albedo=[0.2, 0.7, 0.2, 0.0, 0.0])
+    elif variant == "nested_skies":
+        s["objects"].append({"origin": [1.0, 2.0, 3.0], "r2": 4.0e8, "mtl": {"color": [0.3, 0.0, 0.3], "albedo": [1, 0, 0, 0, 0],
+                                                                               "specular_exponent": 0, "refract_index": 1.0, "sampler": {"kind": 0}}})
+    elif variant == "sky_not_last":
+        s["objects"] = [sky] + [o for o in s["objects"] if o is not sky]  # tie-break order must not matter
+    blob = rt_host.flatten_scene(s)
+    w, h = 160, 90
+    assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1
