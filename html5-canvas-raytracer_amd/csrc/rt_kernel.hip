@@ -202,13 +202,18 @@ template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3
 
 template <bool REFRACT, bool COUNT>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
-                                            v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
+                                            [[maybe_unused]] double *acc, v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
   const sphere_kptr objs = (sphere_kptr)L.objects;
   const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
   const double eps = L.epsilon;
   [[maybe_unused]] const uint32_t enc = L.enclosing;   // index of the enclosing sphere, or ~0u
-  frame<REFRACT> stack[RT_MAX_SEGS];
+#if RT_STRICT
+  constexpr bool FOLD_FORWARD = false;
+#else
+  constexpr bool FOLD_FORWARD = !REFRACT;   // reflection-only scenes: no stack at all (see the descend step)
+#endif
+  [[maybe_unused]] frame<REFRACT> stack[FOLD_FORWARD ? 1 : RT_MAX_SEGS];
   int level = 0;
 #ifdef RT_ABLATE_BOUNCE
   uint32_t segs_left = L.segs ? 1 : 0;
@@ -463,6 +468,41 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           // children are absent or return [0,0,0] (segs == 0, main.js:221): x + 0*a == x
 #pragma unroll
           for (int c = 0; c < 3; c++) ret[c] = maxa(col[c] * a0, min1(col[c] * diffuse + col[c] * specular));
+        } else if constexpr (FOLD_FORWARD) {
+          // Reflection-only recursion is a chain, and each level maps its child's colour x through
+          //   f(x) = max(amb, min(1, ds + a3*x))            (main.js:326-336)
+          // a non-decreasing clamped-affine map.  Compositions of such maps are again clamped-affine, so the
+          // pixel as a function of the ray currently being traced is kept in closed form
+          //   F(x) = max(LO, min(HI, O + S*x))              (S one scalar; O, LO, HI per channel)
+          // and updated on the way DOWN: no stack, no unwinding, any depth.  The ten doubles live in LDS
+          // (lane-major, conflict-free) so they cost no registers; they are touched once per bounce.
+          //   F o f:  S' = S*a3,  O' = O + S*ds,  LO' = clampF(O + S*amb),  HI' = clampF(O + S*max(amb,1))
+          const uint32_t T = RT_WG_THREADS;
+          if (level == 0) {
+            acc[0] = a3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const double A = col[c] * a0;
+              acc[(1 + c) * T] = col[c] * diffuse + col[c] * specular;
+              acc[(4 + c) * T] = A;
+              acc[(7 + c) * T] = __builtin_fmax(A, 1.0);
+            }
+          } else {
+            const double S = acc[0];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const double A = col[c] * a0, D = col[c] * diffuse + col[c] * specular;
+              const double O = acc[(1 + c) * T], LO = acc[(4 + c) * T], HI = acc[(7 + c) * T];
+              const double l2 = __builtin_fma(S, A, O), h2 = __builtin_fma(S, __builtin_fmax(A, 1.0), O);
+              acc[(1 + c) * T] = __builtin_fma(S, D, O);
+              acc[(4 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, l2));
+              acc[(7 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, h2));
+            }
+            acc[0] = S * a3;
+          }
+          p = h; d = r;
+          level++; segs_left--;
+          descend = true;
         } else {
           frame<REFRACT> &fr = stack[level];
 #pragma unroll
@@ -480,33 +520,44 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       }
       if (descend) continue;
 
-      // ---------------- return `ret` to the parents (post-order fold, main.js:268-278, :326-336) ----------------
-      bool resumed = false;
-      while (level > 0) {
-        level--; segs_left++;
-        frame<REFRACT> &fr = stack[level];
-        if constexpr (REFRACT) {
-          if (fr.phase == 0) {
-            fr.re[0] = ret[0] * fr.a3; fr.re[1] = ret[1] * fr.a3; fr.re[2] = ret[2] * fr.a3;
-            if (fr.has_f) {                            // now the refraction child of the same node
-              fr.phase = 1;
-              p = mk(fr.h[0], fr.h[1], fr.h[2]); d = mk(fr.f[0], fr.f[1], fr.f[2]);
-              level++; segs_left--;
-              resumed = true;
-              break;
-            }
+      if constexpr (FOLD_FORWARD) {
+        // the chain ended with colour `ret`: apply the accumulated map once
+        if (level > 0) {
+          const uint32_t T = RT_WG_THREADS;
+          const double S = acc[0];
 #pragma unroll
-            for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c]));
+          for (int c = 0; c < 3; c++) ret[c] = __builtin_fmax(acc[(4 + c) * T], __builtin_fmin(acc[(7 + c) * T], __builtin_fma(S, ret[c], acc[(1 + c) * T])));
+        }
+        break;
+      } else {
+        // ---------------- return `ret` to the parents (post-order fold, main.js:268-278, :326-336) ----------------
+        bool resumed = false;
+        while (level > 0) {
+          level--; segs_left++;
+          frame<REFRACT> &fr = stack[level];
+          if constexpr (REFRACT) {
+            if (fr.phase == 0) {
+              fr.re[0] = ret[0] * fr.a3; fr.re[1] = ret[1] * fr.a3; fr.re[2] = ret[2] * fr.a3;
+              if (fr.has_f) {                            // now the refraction child of the same node
+                fr.phase = 1;
+                p = mk(fr.h[0], fr.h[1], fr.h[2]); d = mk(fr.f[0], fr.f[1], fr.f[2]);
+                level++; segs_left--;
+                resumed = true;
+                break;
+              }
+#pragma unroll
+              for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c]));
+            } else {
+#pragma unroll
+              for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c] + ret[c] * fr.a4));
+            }
           } else {
 #pragma unroll
-            for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + fr.re[c] + ret[c] * fr.a4));
+            for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + ret[c] * fr.a3));
           }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 3; c++) ret[c] = maxa(fr.amb[c], min1(fr.ds[c] + ret[c] * fr.a3));
         }
+        if (!resumed) break;
       }
-      if (!resumed) break;
     }
   }
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
@@ -524,6 +575,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
   __syncthreads();
   const rt_sphere *mtl = (const rt_sphere *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
+  double *acc = lds_raw + mtl_words + tex_words + tid;   // 10 x RT_WG_THREADS doubles, lane-major (product chain kernel only)
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t wave = tid >> 6, lane = tid & 63u;
@@ -554,7 +606,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
-  trace_pixel<REFRACT, COUNT>(L, mtl, tex, o, ray, rgb, cnt);
+  trace_pixel<REFRACT, COUNT>(L, mtl, tex, acc, o, ray, rgb, cnt);
 
   // ---- A10 RGBA8 store ----
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
