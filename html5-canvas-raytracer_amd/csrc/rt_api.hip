@@ -79,7 +79,8 @@ struct rt_scene_dev {
   int device;
   void *d_blob;                  // the uploaded scene blob
   rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
-  rt_geom *d_geom;               // compact geometry table (origin, r2) for the scalar-loaded loops
+  rt_geom *d_geom;               // geometry tables, two orderings: [A: plain, camera, lights][B: plain, camera, lights]
+  rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
   rt_scene_header hd;            // host copy
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
   unsigned lds_bytes;
@@ -156,7 +157,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if ((rc = ensure_device(device))) return rc;
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
-  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr;
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -185,28 +186,46 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     rt_sphere *pob = (rt_sphere *)(patched.data() + hd->objects_offset);
     for (uint32_t i = 0; i < hd->n_objects; i++) pob[i].reserved = 1.0 / sqrt(pob[i].r2);
   }
-  // geometry tables: [0,N) plain, [N,2N) anchored at the camera, [2N, 2N + NL*N) anchored at each light
+  // Geometry tables (32-byte records), per ordering: [0,N) plain {origin, r2}; [N,2N) anchored at the camera
+  // {o - cam, |o - cam|^2 - r2}; [2N, 2N + NL*N) anchored at each light.  Ordering A = the scene's own order
+  // (strict kernel, counting variant).  Ordering B = the enclosing sphere moved to the end, so the product
+  // kernel's loops run over [0, N-1) and never test it.
   const uint32_t NO = hd->n_objects;
-  std::vector<rt_geom> geom((size_t)NO * (2 + hd->n_lights));
+  const size_t per_order = (size_t)NO * (2 + hd->n_lights);
+  const bool has_b = s->enclosing != ~0u;
+  std::vector<rt_geom> geom(per_order * (has_b ? 2 : 1));
+  std::vector<rt_sphere> objs_b;
   auto anchored = [&](const rt_sphere &o, const double a[3]) {
     const double lx = o.origin[0] - a[0], ly = o.origin[1] - a[1], lz = o.origin[2] - a[2];
     return rt_geom{lx, ly, lz, (lx * lx + ly * ly + lz * lz) - o.r2};
   };
-  for (uint32_t i = 0; i < NO; i++) {
-    geom[i] = rt_geom{ob[i].origin[0], ob[i].origin[1], ob[i].origin[2], ob[i].r2};
-    geom[NO + i] = anchored(ob[i], hd->cam_origin);
-    for (uint32_t k = 0; k < hd->n_lights; k++) geom[(size_t)NO * (2 + k) + i] = anchored(ob[i], s->lights[k]);
+  auto fill = [&](const rt_sphere *src, rt_geom *dst) {
+    for (uint32_t i = 0; i < NO; i++) {
+      dst[i] = rt_geom{src[i].origin[0], src[i].origin[1], src[i].origin[2], src[i].r2};
+      dst[NO + i] = anchored(src[i], hd->cam_origin);
+      for (uint32_t k = 0; k < hd->n_lights; k++) dst[(size_t)NO * (2 + k) + i] = anchored(src[i], s->lights[k]);
+    }
+  };
+  const rt_sphere *pob_a = (const rt_sphere *)(patched.data() + hd->objects_offset);
+  fill(pob_a, geom.data());
+  if (has_b) {
+    for (uint32_t i = 0; i < NO; i++) if (i != s->enclosing) objs_b.push_back(pob_a[i]);
+    objs_b.push_back(pob_a[s->enclosing]);
+    fill(objs_b.data(), geom.data() + per_order);
   }
   hipError_t e = hipMalloc(&s->d_blob, bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
   if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
+  if (e == hipSuccess && has_b) e = hipMalloc((void **)&s->d_objects_b, objs_b.size() * sizeof(rt_sphere));
+  if (e == hipSuccess && has_b) e = hipMemcpy(s->d_objects_b, objs_b.data(), objs_b.size() * sizeof(rt_sphere), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_blob, patched.data(), bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_texdesc, descs, sizeof descs, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (s->d_blob) (void)hipFree(s->d_blob);
     if (s->d_texdesc) (void)hipFree(s->d_texdesc);
     if (s->d_geom) (void)hipFree(s->d_geom);
+    if (s->d_objects_b) (void)hipFree(s->d_objects_b);
     delete s;
     return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
   }
@@ -220,6 +239,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   (void)hipFree(s->d_blob);
   (void)hipFree(s->d_texdesc);
   (void)hipFree(s->d_geom);
+  if (s->d_objects_b) (void)hipFree(s->d_objects_b);
   delete s;
 }
 
@@ -241,11 +261,17 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   rt_launch L;
   memset(&L, 0, sizeof L);
   const uint8_t *db = (const uint8_t *)s->d_blob;
-  L.objects = (const rt_sphere *)(db + hd.objects_offset);
+  // ordering B (enclosing sphere last, outside the loops) for the product kernel; the strict kernel and the
+  // counting variant walk the scene in its own order so that they stay literal / count what the reference counts
+  const bool order_b = s->d_objects_b && !(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT));
+  const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (2 + hd.n_lights) : 0);
+  L.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
   L.textures = s->d_texdesc;
-  L.geom = s->d_geom;
-  L.geom_cam = s->d_geom + hd.n_objects;
-  L.geom_light = s->d_geom + 2 * (size_t)hd.n_objects;
+  L.geom = gt;
+  L.geom_cam = gt + hd.n_objects;
+  L.geom_light = gt + 2 * (size_t)hd.n_objects;
+  L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
+  L.enclosing = order_b ? hd.n_objects - 1 : ~0u;
   L.texel_base = db;
   L.out = (uint32_t *)d_out;
   L.counters = D.d_counters;
@@ -264,7 +290,6 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
 
   if (tiles->n_tiles > 65535u) return fail(RT_ERR_INVALID, "n_tiles %u > 65535 (grid z)", tiles->n_tiles);
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
-  L.enclosing = s->enclosing;
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
 

@@ -207,7 +207,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
   const double eps = L.epsilon;
-  [[maybe_unused]] const uint32_t enc = L.enclosing;   // index of the enclosing sphere, or ~0u
+  const uint32_t NLOOP = L.n_loop;                      // spheres the per-ray loops walk: N, or N-1 with an enclosing sphere
+  const uint32_t enc = L.enclosing;                      // device index of the enclosing sphere (== NLOOP), or ~0u
 #if RT_STRICT
   constexpr bool FOLD_FORWARD = false;
 #else
@@ -231,69 +232,65 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // The winner is kept as one int, 2*i + inside, so a candidate costs one 64-bit and one
       // 32-bit select.
       double ht = RT_INF; int hcode = -1;
+      // One candidate: the sqrt and the bookkeeping stay inside the hit branch (RT_PIN).
+#define RT_CAND(IDX, TCA, DISC)                                                               \
+      if (!((DISC) < 0.0)) {                                                                  \
+        RT_PIN();                                                                             \
+        const double thc_ = rt_sqrt_nn(DISC);                                                 \
+        const double t0_ = (TCA) - thc_, t1_ = (TCA) + thc_;                                  \
+        const bool in_ = (t0_ < eps);                                                         \
+        const double t_ = in_ ? t1_ : t0_;                                                    \
+        const bool closer_ = (t_ < ht) && !(t_ < eps);   /* strict <: first wins */           \
+        ht = closer_ ? t_ : ht;                                                               \
+        hcode = closer_ ? ((int)(2u * (IDX)) + (in_ ? 1 : 0)) : hcode;                        \
+      }
+      // generic form, the reference's own (main.js:422-425): disc = r2 - d2
+#define RT_GENERIC(IDX, G)                                                                    \
+      {                                                                                       \
+        const v3 Lv_ = mk((G).ox - p.x, (G).oy - p.y, (G).oz - p.z);                          \
+        const double tca_ = dot(d, Lv_);                                                      \
+        const double disc_ = (G).r2 - (dot(Lv_, Lv_) - tca_ * tca_);                          \
+        RT_CAND(IDX, tca_, disc_)                                                             \
+      }
+      // anchored form (origin = camera): disc = tca^2 - Ca
+#define RT_ANCHORED(IDX, G)                                                                   \
+      {                                                                                       \
+        const double tca_ = d.x * (G).ox + d.y * (G).oy + d.z * (G).oz;                       \
+        const double disc_ = __builtin_fma(tca_, tca_, -(G).r2);                              \
+        RT_CAND(IDX, tca_, disc_)                                                             \
+      }
+#define RT_LOAD(TAB, I) rt_geom{(TAB)[I].ox, (TAB)[I].oy, (TAB)[I].oz, (TAB)[I].r2}
+      // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
+      // the compiler's runtime unrolling); the two s_load_dwordx8 of a pair are issued together.
 #if !RT_STRICT
       if (level == 0 && primary) {
-        // primary rays: anchored at the camera
         const geom_kptr ga = (geom_kptr)L.geom_cam;
-#pragma unroll 2
-        for (uint32_t i = 0; i < N; i++) {
-          if (i == enc) continue;
-          const rt_geom g = {ga[i].ox, ga[i].oy, ga[i].oz, ga[i].r2};
-          const double tca = d.x * g.ox + d.y * g.oy + d.z * g.oz;
-          const double disc = __builtin_fma(tca, tca, -g.r2);        // r2 - d2
-          if (!(disc < 0.0)) {
-            RT_PIN();
-            const double thc = rt_sqrt_nn(disc);
-            const double t0 = tca - thc, t1 = tca + thc;
-            const bool in = (t0 < eps);
-            const double t = in ? t1 : t0;
-            const bool closer = (t < ht) && !(t < eps);               // strict <: first wins
-            ht = closer ? t : ht;
-            hcode = closer ? ((int)(2u * i) + (in ? 1 : 0)) : hcode;
-          }
+        uint32_t i = 0;
+        for (; i + 2 <= NLOOP; i += 2) {
+          const rt_geom g0 = RT_LOAD(ga, i), g1 = RT_LOAD(ga, i + 1);
+          RT_ANCHORED(i, g0) RT_ANCHORED(i + 1, g1)
         }
+        if (i < NLOOP) { const rt_geom g0 = RT_LOAD(ga, i); RT_ANCHORED(i, g0) }
       } else
 #endif
       {
-#pragma unroll 2
-        for (uint32_t i = 0; i < N; i++) {
-#if !RT_STRICT
-          if (i == enc) continue;
-#endif
-          const rt_geom g = {geom[i].ox, geom[i].oy, geom[i].oz, geom[i].r2};
-          const v3 Lv = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
-          const double tca = dot(d, Lv);
-          const double d2 = dot(Lv, Lv) - tca * tca;
-          if (!(d2 > g.r2)) {
-            RT_PIN();
-            const double thc = rt_sqrt_nn(g.r2 - d2);
-            const double t0 = tca - thc, t1 = tca + thc;
-            const bool in = (t0 < eps);
-            const double t = in ? t1 : t0;
-            const bool closer = (t < ht) && !(t < eps);               // strict <: first wins
-            ht = closer ? t : ht;
-            hcode = closer ? ((int)(2u * i) + (in ? 1 : 0)) : hcode;
-          }
+        uint32_t i = 0;
+        for (; i + 2 <= NLOOP; i += 2) {
+          const rt_geom g0 = RT_LOAD(geom, i), g1 = RT_LOAD(geom, i + 1);
+          RT_GENERIC(i, g0) RT_GENERIC(i + 1, g1)
         }
+        if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
       }
-#if !RT_STRICT
-      // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) can
-      // only be the closest hit of a ray that hits nothing else, and such a ray starts inside it: one
-      // root behind, one ahead.  Only the lanes still without a hit evaluate it.
-      if (enc < N && hcode < 0) {
-        const rt_geom g = {geom[enc].ox, geom[enc].oy, geom[enc].oz, geom[enc].r2};
-        const v3 Lv = mk(g.ox - p.x, g.oy - p.y, g.oz - p.z);
-        const double tca = dot(d, Lv);
-        const double d2 = dot(Lv, Lv) - tca * tca;
-        if (!(d2 > g.r2)) {
-          const double thc = rt_sqrt_nn(g.r2 - d2);
-          const double t0 = tca - thc, t1 = tca + thc;
-          const bool in = (t0 < eps);
-          const double t = in ? t1 : t0;
-          if (!(t < eps) && (t < RT_INF)) { ht = t; hcode = (int)(2u * enc) + (in ? 1 : 0); }
-        }
+      // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) is
+      // kept LAST in the device tables and outside the loops above: it can only be the closest hit of a
+      // ray that hits nothing else.  Only the lanes still without a hit evaluate it.
+      if (enc != ~0u && hcode < 0) {
+        const rt_geom g0 = RT_LOAD(geom, enc);
+        RT_GENERIC(enc, g0)
       }
-#endif
+#undef RT_ANCHORED
+#undef RT_GENERIC
+#undef RT_CAND
       primary = false;
       if (COUNT) cnt[2] += N;
       const int hi = hcode >> 1;
@@ -390,48 +387,60 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             if (COUNT) cnt[1]++;
             // Shadow scan (main.js:293-304).  `alive` is the per-lane "not yet fully blocked" flag; the
             // loop leaves early only when every lane of the wave is blocked (exec-mask loop exit).
+            // Shadow scan (main.js:293-304) over every sphere but the one just hit (q3).  A fully blocked lane
+            // keeps li == 0 whatever follows, so leaving the loop is a pure shortcut, taken per pair.
             uint32_t tests = 0;
+            bool blocked = false;
 #if !RT_STRICT
             // walked from the light: origin = light k (uniform), direction = -sv, the hit point is at llen
-            const geom_kptr gl = (geom_kptr)L.geom_light + (size_t)k * N;
-#endif
-#ifdef RT_ABLATE_SHADOW
-            for (uint32_t j = 0; j < 0; j++) {
+            const geom_kptr gl = (geom_kptr)L.geom_light + (size_t)k * L.n_objects;
+#define RT_SDISC(G, TC, DISC)                                                                 \
+            const double TC = -(sv.x * (G).ox + sv.y * (G).oy + sv.z * (G).oz);               \
+            const double DISC = __builtin_fma(TC, TC, -(G).r2);
+#define RT_SROOTS(TC, THC, T0, T1) const double T0 = llen - (TC + THC), T1 = llen - (TC - THC);
 #else
-            for (uint32_t j = 0; j < N; j++) {
+            const geom_kptr gl = geom;
+#define RT_SDISC(G, TC, DISC)                                                                 \
+            const v3 Lv_ = mk((G).ox - h.x, (G).oy - h.y, (G).oz - h.z);                      \
+            const double TC = dot(sv, Lv_);                                                   \
+            const double DISC = (G).r2 - (dot(Lv_, Lv_) - TC * TC);
+#define RT_SROOTS(TC, THC, T0, T1) const double T0 = TC - THC, T1 = TC + THC;
 #endif
-              if ((int)j == hi) continue;                              // main.js:294 (q3)
-              tests++;                                                 // counts the reference's intersectSphere calls
-#if !RT_STRICT
-              if (j == enc) continue;                                  // never between a surface point and a light
-#endif
-#if !RT_STRICT
-              const rt_geom g = {gl[j].ox, gl[j].oy, gl[j].oz, gl[j].r2};
-              const double tcl = -(sv.x * g.ox + sv.y * g.oy + sv.z * g.oz);   // along -sv, from the light
-              const double disc = __builtin_fma(tcl, tcl, -g.r2);
-              if (!(disc < 0.0)) {
-                RT_PIN();
-                const double thc = rt_sqrt_nn(disc);
-                const double t0 = llen - (tcl + thc), t1 = llen - (tcl - thc);   // back to distances from the hit point
-#else
-              const rt_geom g = {geom[j].ox, geom[j].oy, geom[j].oz, geom[j].r2};
-              const v3 Lv = mk(g.ox - h.x, g.oy - h.y, g.oz - h.z);
-              const double tca = dot(sv, Lv);
-              const double d2 = dot(Lv, Lv) - tca * tca;
-              if (!(d2 > g.r2)) {
-                RT_PIN();
-                const double thc = rt_sqrt_nn(g.r2 - d2);
-                const double t0 = tca - thc, t1 = tca + thc;
-#endif
-                const double t = (t0 < eps) ? t1 : t0;
-                if ((t < llen) && !(t < eps)) {
-                  RT_PIN();
-                  const double oa4 = objs[j].albedo[4];
-                  if (oa4 != 0.0) li = rt_div(li, oa4);                // transparent occluder brightens (q2)
-                  else { li = 0.0; break; }
-                }
-              }
+#define RT_SHADOW(J, G)                                                                       \
+            {                                                                                 \
+              const bool other_ = ((int)(J) != hi);                                           \
+              if (COUNT && other_ && !blocked) tests++;                                       \
+              RT_SDISC(G, tc_, disc_)                                                         \
+              if (other_ && !(disc_ < 0.0) && !blocked) {                                     \
+                RT_PIN();                                                                     \
+                const double thc_ = rt_sqrt_nn(disc_);                                        \
+                RT_SROOTS(tc_, thc_, t0_, t1_)                                                \
+                const double t_ = (t0_ < eps) ? t1_ : t0_;                                    \
+                if ((t_ < llen) && !(t_ < eps)) {                                             \
+                  RT_PIN();                                                                   \
+                  const double oa4_ = objs[J].albedo[4];                                      \
+                  if (oa4_ != 0.0) li = rt_div(li, oa4_);   /* transparent occluder brightens (q2) */ \
+                  else { li = 0.0; blocked = true; }                                          \
+                }                                                                             \
+              }                                                                               \
             }
+#ifdef RT_ABLATE_SHADOW
+            const uint32_t NS = 0;
+#else
+            const uint32_t NS = NLOOP;
+#endif
+            if (COUNT || li != 0.0) {                  // li == 0 on entry (an earlier light was blocked) cannot change
+              uint32_t j = 0;
+              for (; j + 2 <= NS; j += 2) {
+                const rt_geom g0 = RT_LOAD(gl, j), g1 = RT_LOAD(gl, j + 1);
+                RT_SHADOW(j, g0) RT_SHADOW(j + 1, g1)
+                if (blocked) break;
+              }
+              if (j < NS && !blocked) { const rt_geom g0 = RT_LOAD(gl, j); RT_SHADOW(j, g0) }
+            }
+#undef RT_SHADOW
+#undef RT_SROOTS
+#undef RT_SDISC
             if (COUNT) cnt[2] += tests;
             if (li == 0.0) continue;
 #if RT_STRICT
@@ -560,6 +569,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       }
     }
   }
+#undef RT_LOAD
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
 }
 
