@@ -4,27 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one frame: every rank renders its interleaved row tiles
-of the frame with the HIP kernel (through the C ABI, rt_render_tiles_device), the tiles are gathered
-to rank 0 over RCCL (torch.distributed, backend "nccl") and de-interleaved into the final RGBA8
-frame in rank 0's HBM.  At N=1 a step is exactly one kernel launch writing the frame.
+Workload: BASELINE configs[2] — 3840x2160, the 8-sphere "H8" scene, 2 lights, depth 3 — at every N.
 
-Workload: BASELINE configs[2] — 3840x2160, the 8-sphere "H8" scene, 2 lights, depth 3 — at N=1.
-For N>1 the frame is scaled at constant aspect so that every GPU keeps one 4K frame's worth of
-pixels (N=4 is exactly configs[3], 7680x4320): weak scaling.  The scene is resident in HBM before
-the timed region; the frame stays in HBM (the PCIe copy-out rate is quoted in DESIGN.md, never here).
+N = 1: a step is ONE kernel launch writing one 3840x2160 frame (the hot path, main.js:184-199 +
+:216-451, through the C ABI's rt_render_tiles_device).
+
+N > 1 (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI): a step is a BATCH of N
+frames.  Each frame is sharded by interleaved 16-row tiles across the N ranks; every rank renders its
+tiles of all N frames in one launch (rt_render_batch_device), ONE all-to-all sends the band of frame f to
+rank f, and each rank de-interleaves one whole frame in its own HBM.  Per-GPU work per step is one frame's
+worth of pixels at every N (weak scaling), every frame is reassembled by a single RCCL collective, and the
+collective uses all N(N-1) directed xGMI links at once (a gather to one root would be bound by that
+root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels, three links' worth).  The
+exchange of step k overlaps the render of step k+1 (two buffer slots).  The scene is resident in HBM
+before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the HBM-store roofline the
-metric names (4 algorithmic bytes per pixel) — the path is FP64-VALU bound, so that fraction is
-small by construction; the `fp64_valu` object prices it against the binding bound.
-`cpu_baseline` is the oracle's JS restatement (bit-identical to main.js, see tests/test_oracle.py)
-on one host thread, on a bounded sample of rows of the same frame.
+metric names (4 algorithmic bytes per pixel); the path is FP64-VALU bound, so `fp64_valu` prices it
+against the binding bound.  `cpu_baseline` is the oracle's JS restatement (bit-identical to main.js, see
+tests/test_oracle.py) on one host thread over a bounded sample of rows of the same frame (N=1 only).
 """
 import argparse
 import json
-import math
 import os
-import subprocess
 import sys
 import time
 
@@ -35,24 +37,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (FMA) peak = half the 157.3 TF FP32 vector rate
 TILE_ROWS = 16
-
-
-def frame_size_for(n):
-    """One 4K frame's worth of pixels per GPU at constant 16:9 aspect; whole 32x8 workgroup tiles."""
-    if n == 1:
-        return 3840, 2160
-    s = math.sqrt(n)
-    return int(round(3840 * s / 32)) * 32, int(round(2160 * s / TILE_ROWS)) * TILE_ROWS
+FRAME_W, FRAME_H = 3840, 2160
 
 
 def cpu_baseline(scene_name, w, h):
     """Oracle leg (checker code, timed beside the GPU; never on the product path)."""
     import oracle_util as ou
     rows = min(h, 1080)
-    cores = 1
     if ou.node_path():
         r = ou.node_cli("time", ou.scene_json(scene_name), w, h, rows, timeout=900)
-        return {"value": round(r["mpixel_per_s"], 4), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+        return {"value": round(r["mpixel_per_s"], 4), "unit": "Mpixel/s", "cores": 1, "kind": "port",
                 "sample": "%d of %d rows evenly spaced (%d pixels), oracle/restate.js (bit-identical to main.js) under node %s, 1 thread, "
                           "after an untimed JIT warm-up pass" % (rows, h, r["pixels"], r["node"]),
                 "mray_per_s": round(r["rays"] / r["ms"] / 1e3, 4), "host_cpus": os.cpu_count()}
@@ -63,7 +57,7 @@ def cpu_baseline(scene_name, w, h):
     t0 = time.perf_counter()
     ou.c_oracle_rows(blob, w, h, ys)
     dt = time.perf_counter() - t0
-    return {"value": round(rows * w / dt / 1e6, 4), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+    return {"value": round(rows * w / dt / 1e6, 4), "unit": "Mpixel/s", "cores": 1, "kind": "port",
             "sample": "%d of %d rows evenly spaced, oracle/rt_oracle.c (gcc -O2, no FMA), 1 thread (node not installed)" % (rows, h),
             "host_cpus": os.cpu_count()}
 
@@ -74,16 +68,16 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="h8")
-    ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=FRAME_W)
+    ap.add_argument("--height", type=int, default=FRAME_H)
     ap.add_argument("--strict-fp", action="store_true", help="time the no-FMA kernel variant instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     import rt_host
+    import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +87,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the render path has no CPU fallback")
     # RT_BENCH_REHEARSE=1: rehearsal of the N>1 control flow on a ONE-GPU box — every rank shares GPU 0 and
-    # the gather goes over gloo through host memory.  Never a measurement (the JSON says so).
+    # the exchange goes over gloo through host memory.  Never a measurement (the JSON says so).
     rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
@@ -105,57 +99,54 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    w, h = frame_size_for(world)
-    if args.width and args.height:
-        w, h = args.width, args.height
+    w, h = args.width, args.height
     scene = rt_host.load_scene(args.scene)
     ss = scene.get("supersample", 1)
     lib = rt_host.load_library()
     renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
     flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
 
-    import shard
     plan = shard.TilePlan(w, h, TILE_ROWS, world)
-    per_rank, band_rows = plan.tiles_per_rank, plan.band_rows
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
     # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    if world == 1:
-        frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-        bands = None
-    else:
-        bands = [torch.empty((band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
-        frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-        gathered = [torch.empty((world, band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if rank == 0 else None
-    my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
-    host_gathered = torch.empty((world, band_rows, w, 4), dtype=torch.uint8) if (rehearse and rank == 0) else None
+    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)          # this rank's reassembled frame
     whole = rt_host.RtTiles(h, 0, 1, 1)
+    my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
+    if world > 1:
+        send = [torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_recv = torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8) if rehearse else None
+    pending = []      # (work, slot) of exchanges in flight; at most 2
 
-    pending = []      # (work, slot) of gathers in flight; at most 2
+    def render_step(slot):
+        if world == 1:
+            renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
+        else:   # this rank's tiles of all `world` frames of the batch, one launch
+            renderer.render_batch(w, h, send[slot].data_ptr(), my_tiles, world, plan.band_bytes, stream=stream, flags=flags)
 
     def finish(slot_work):
         work, slot = slot_work
-        work.wait()                                              # current stream waits for the gather
-        if rank == 0:
-            if rehearse:
-                gathered[slot].copy_(host_gathered)
-            shard.deinterleave(plan, gathered[slot], frame, lib=lib, device_index=dev_index, stream=stream)
+        work.wait()                                              # current stream waits for the exchange
+        if rehearse:
+            recv[slot].copy_(host_recv)
+        shard.deinterleave(plan, recv[slot], frame, lib=lib, device_index=dev_index, stream=stream)
 
     def step(k):
         if world == 1:
-            renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
+            render_step(0)
             return
         slot = k & 1
-        if len(pending) == 2:                                    # the gather that last used this slot
+        if len(pending) == 2:                                    # the exchange that last used this slot
             finish(pending.pop(0))
-        renderer.render_tiles(w, h, bands[slot].data_ptr(), my_tiles, stream=stream, flags=flags)
+        render_step(slot)
         if rehearse:
-            work = shard.gather_bands(bands[slot].cpu(), host_gathered if rank == 0 else None, dst=0, async_op=True)
+            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
         else:
-            work = shard.gather_bands(bands[slot], gathered[slot] if rank == 0 else None, dst=0, async_op=True)
+            work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
         pending.append((work, slot))                             # overlaps with the next step's render
 
     def drain():
@@ -179,24 +170,22 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     # ---- dominant kernel: average launch duration, HIP events on the launch stream ----
-    tiles = whole if world == 1 else my_tiles
-    target = frame if world == 1 else bands[0]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 20))]
     for a, b in evs:
         a.record()
-        renderer.render_tiles(w, h, target.data_ptr(), tiles, stream=stream, flags=flags)
+        render_step(0)
         b.record()
     torch.cuda.synchronize()
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-    launch_pixels = plan.pixels_of(rank) if world > 1 else w * h
+    launch_pixels = w * h if world == 1 else world * plan.pixels_of(rank)
 
-    # one more (untimed) frame on every rank, checked on rank 0 against the reference's rows
+    # one more (untimed) step on every rank; rank 0 checks its reassembled frame against the reference's rows
     step(0)
     drain()
     torch.cuda.synchronize()
@@ -208,29 +197,33 @@ def main():
                 got = frame[f["rows"]].cpu().numpy().reshape(-1)
                 max_lsb = ou.max_lsb(got, ou.golden_frame(f))[0]
         # work counters from the instrumented variant (untimed)
-        st = renderer.render_tiles(w, h, target.data_ptr(), tiles, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
+        st = renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
         rays_pp, shadow_pp, tests_pp = st.rays / st.pixels, st.shadow_rays / st.pixels, st.sphere_tests / st.pixels
-        pixels = w * h
-        total_pixels = pixels * args.steps
+        frames_per_step = world
+        total_pixels = w * h * frames_per_step * args.steps
         value = total_pixels / elapsed / 1e6
         flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
         algo_bytes = 4.0 * launch_pixels
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
             key = "%s_%dx%d" % (args.scene, w, h)
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
+        if world == 1:
+            how = "one launch per frame"
+        else:
+            how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
+                   "reassembles frame f on rank f, de-interleave in HBM; exchange of step k overlaps render of step k+1" % (world, TILE_ROWS, world))
         out = {
             "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; %s" % (
-                args.scene, len(scene["objects"]), len(scene["lights"]), scene["segs"], ss, w, h,
-                "one launch per frame" if world == 1 else "interleaved %d-row tiles over %d ranks + RCCL gather to rank 0 + de-interleave" % (TILE_ROWS, world)),
-                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "pixels_per_gpu": pixels // world,
+                args.scene, len(scene["objects"]), len(scene["lights"]), scene["segs"], ss, w, h, how),
+                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step, "pixels_per_gpu_per_step": w * h,
                 **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {})},
             "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
             "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
@@ -242,6 +235,9 @@ def main():
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
                           "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
         }
+        if world > 1:
+            out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
+                               "bytes_per_directed_link_per_step": plan.band_bytes}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.scene, w, h)

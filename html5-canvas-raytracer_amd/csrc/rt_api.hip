@@ -246,7 +246,14 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
 // ------------------------------------------------------------------------------------ launch
 extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, void *d_out, void *hip_stream,
                                       uint32_t flags, rt_stats *stats) {
+  return rt_render_batch_device(s, w, h, tiles, 1u, d_out, 0u, hip_stream, flags, stats);
+}
+
+extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out,
+                                      uint64_t frame_stride_bytes, void *hip_stream, uint32_t flags, rt_stats *stats) {
   if (!s || !tiles || !d_out) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
+  if (n_frames == 0 || n_frames > 65535u) return fail(RT_ERR_INVALID, "n_frames %u not in 1..65535", n_frames);
+  if ((frame_stride_bytes & 3u) != 0) return fail(RT_ERR_INVALID, "frame stride must be a multiple of 4 bytes");
   if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "frame size %ux%u not in 1..65536", w, h);
   if (tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0) return fail(RT_ERR_INVALID, "empty tile set");
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows > (1ull << 24)) return fail(RT_ERR_INVALID, "too many rows in one call");
@@ -288,7 +295,13 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
   memcpy(L.lights, s->lights, sizeof L.lights);
 
-  if (tiles->n_tiles > 65535u) return fail(RT_ERR_INVALID, "n_tiles %u > 65535 (grid z)", tiles->n_tiles);
+  const uint32_t rows_per_wg = ss2 ? 2u : RT_TILE_H;
+  L.rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
+  L.rb_shift = ~0u;
+  for (uint32_t b = 0; b < 31; b++) if (L.rb_per_tile == (1u << b)) L.rb_shift = b;
+  if ((uint64_t)tiles->n_tiles * L.rb_per_tile > 65535u) return fail(RT_ERR_INVALID, "%u tiles x %u row blocks exceed the grid's y limit (65535)", tiles->n_tiles, L.rb_per_tile);
+  L.n_frames = n_frames;
+  L.frame_stride = frame_stride_bytes / 4u;
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
@@ -314,7 +327,7 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
       const uint64_t r0 = (uint64_t)(tiles->tile_first + (uint64_t)i * tiles->tile_stride) * tiles->tile_rows;
       if (r0 < h) px += ((r0 + tiles->tile_rows <= h) ? tiles->tile_rows : (h - r0)) * (uint64_t)w;
     }
-    stats->pixels = px;
+    stats->pixels = px * n_frames;
     if (count) {
       unsigned long long c[3];
       HIP_TRY(hipMemcpy(c, D.d_counters, sizeof c, hipMemcpyDeviceToHost));

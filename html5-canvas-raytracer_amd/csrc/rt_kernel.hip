@@ -589,8 +589,14 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  // grid = (tiles across the frame, row blocks per tile, tiles of this call): no integer division anywhere
-  const uint32_t tile_x = blockIdx.x, row_block = blockIdx.y, tile_i = blockIdx.z;
+  // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
+  // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
+  // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
+  const uint32_t tile_x = blockIdx.x, frame_i = blockIdx.z;
+  uint32_t tile_i, row_block;
+  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
+  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
+  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
   uint32_t px, trow, sub = 0;                          // trow = row inside tile `tile_i`
   if (!SS2) { px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); trow = row_block * RT_TILE_H + (lane >> 3); }
   else { const uint32_t q = lane >> 2; sub = lane & 3u; px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); trow = row_block * 2u + (q >> 3); }
@@ -621,14 +627,14 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
   // ---- A10 RGBA8 store ----
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
   if (!SS2) {
-    if (valid) L.out[(size_t)lrow * L.w + px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+    if (valid) L.out[(size_t)frame_i * L.frame_stride + (size_t)lrow * L.w + px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
   } else {
     // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields)
     uint32_t packed = r8 | (g8 << 10) | (b8 << 20);
     packed += __shfl_xor(packed, 1);
     packed += __shfl_xor(packed, 2);
     const uint32_t R = ((packed & 1023u) + 2u) >> 2, G = (((packed >> 10) & 1023u) + 2u) >> 2, B = (((packed >> 20) & 1023u) + 2u) >> 2;
-    if (valid && sub == 0u) L.out[(size_t)lrow * L.w + px] = R | (G << 8) | (B << 16) | 0xff000000u;
+    if (valid && sub == 0u) L.out[(size_t)frame_i * L.frame_stride + (size_t)lrow * L.w + px] = R | (G << 8) | (B << 16) | 0xff000000u;
   }
 
   if (COUNT) {
@@ -645,9 +651,9 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 
 // Host-side launcher for this translation unit's kernels.  Returns a hipError_t as int.
 extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned lds_bytes, hipStream_t stream) {
-  // x: 32-pixel tiles across the frame; y: row blocks (8 rows, or 2 when supersampling) per tile; z: tiles
-  const unsigned rows_per_wg = ss2 ? 2u : RT_TILE_H;
-  const dim3 grid(L->tiles_x, (L->tile_rows + rows_per_wg - 1) / rows_per_wg, L->n_tiles), block(RT_WG_THREADS);
+  // x: 32-pixel tiles across the frame; y: tiles x row blocks (8 rows, or 2 when supersampling); z: frames
+  (void)ss2;
+  const dim3 grid(L->tiles_x, L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S) hipLaunchKernelGGL((rt_trace<R, C, S>), grid, block, lds_bytes, stream, *L)
   if (!count) {
     if (!refract) { if (!ss2) RT_CASE(false, false, false); else RT_CASE(false, false, true); }

@@ -143,6 +143,8 @@ ABI = {
     "rt_scene_free": (None, [C.c_void_p]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_void_p, C.c_void_p,
                                          C.c_uint32, C.POINTER(RtStats)]),
+    "rt_render_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_uint32, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
     "rt_render": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
     "rt_alloc_pinned": (C.c_void_p, [C.c_size_t]),
     "rt_free_pinned": (None, [C.c_void_p]),
@@ -205,6 +207,15 @@ class Renderer:
         rc = self.lib.rt_render_tiles_device(self.handle, w, h, C.byref(t), C.c_void_p(d_out), C.c_void_p(stream or 0),
                                              flags, C.byref(st) if st is not None else None)
         _check(self.lib, rc, "rt_render_tiles_device")
+        return st
+
+    def render_batch(self, w, h, d_out, tiles, n_frames, frame_stride_bytes, stream=None, flags=0, want_stats=False):
+        """n_frames frames' worth of `tiles` in ONE launch; frame f lands at d_out + f*frame_stride_bytes."""
+        t = tiles if isinstance(tiles, RtTiles) else RtTiles(*tiles)
+        st = RtStats() if want_stats else None
+        rc = self.lib.rt_render_batch_device(self.handle, w, h, C.byref(t), n_frames, C.c_void_p(d_out), frame_stride_bytes,
+                                             C.c_void_p(stream or 0), flags, C.byref(st) if st is not None else None)
+        _check(self.lib, rc, "rt_render_batch_device")
         return st
 
     def close(self):

@@ -7,8 +7,14 @@ floor rows, so contiguous bands would be badly balanced); each rank renders its 
 into a band, ONE gather (RCCL when the tensors are on GPUs, gloo in the CPU tests) brings the bands to
 rank 0, and one de-interleave pass puts the rows in frame order.
 
+Throughput form (what bench.py times): a step is a BATCH of `world` frames.  Every rank renders its row
+tiles of all `world` frames (one launch, rt_render_batch_device), then ONE all-to-all sends the band of
+frame f to rank f, so each rank reassembles one whole frame per step.  On a point-to-point xGMI full mesh
+that uses every directed link at once (each carries 1/world of a frame), where a gather to a single root
+would funnel every band through the root's 7 inbound links and leave the other 49 idle.
+
 Used by bench.py (GPU, backend "nccl") and by tests/test_shard_gloo.py (CPU, backend "gloo",
-world_size 2) — the same code path, only the band producer differs.
+world_size 2 and 3) — the same code path, only the band producer differs.
 """
 from dataclasses import dataclass
 
@@ -58,6 +64,14 @@ def gather_bands(band, gathered, dst=0, async_op=False):
     import torch.distributed as dist
     recv = list(gathered.unbind(0)) if dist.get_rank() == dst else None
     return dist.gather(band, recv, dst=dst, async_op=async_op)
+
+
+def exchange_bands(send, recv, async_op=False):
+    """One all-to-all over a batch of `world` frames: send[f] is this rank's band of frame f (shape
+    [world, band_rows, w, 4]); afterwards recv[g] is rank g's band of frame `rank` — the layout
+    deinterleave() expects."""
+    import torch.distributed as dist
+    return dist.all_to_all_single(recv.view(-1), send.view(-1), async_op=async_op)
 
 
 def deinterleave(plan, gathered, frame, lib=None, device_index=0, stream=0):

@@ -148,6 +148,13 @@ void rt_scene_free(rt_scene_dev *scene);
 int rt_render_tiles_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles,
                            void *d_out_rgba, void *hip_stream, uint32_t flags, rt_stats *stats);
 
+/* The same for a BATCH of n_frames frames in one launch (grid z = frame): frame f's tiles go to
+ * d_out_rgba + f*frame_stride_bytes.  All frames use `scene` (synthetic batches; a real animation uploads one
+ * scene per frame and calls rt_render_tiles_device per frame).  Used by the multi-GPU plan, where a step
+ * renders this rank's row tiles of N frames and one all-to-all reassembles frame f on rank f. */
+int rt_render_batch_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames,
+                           void *d_out_rgba, uint64_t frame_stride_bytes, void *hip_stream, uint32_t flags, rt_stats *stats);
+
 /* render(width,height,scene): whole frame into HOST memory (any host pointer; memory from
  * rt_alloc_pinned makes the copy-out DMA directly).  With more than one GPU in use the
  * frame is sharded by interleaved row tiles and reassembled on GPU 0 with one RCCL gather

@@ -42,6 +42,29 @@ def main():
         ok = int(np.array_equal(frame.numpy(), whole))
         assert sum(plan.pixels_of(r) for r in range(world)) == w * h
         print("DIST_RESULT world=%d identical=%d" % (world, ok), flush=True)
+    # ---- throughput form: a batch of `world` frames, one all-to-all, every rank reassembles one frame.
+    # The frames differ (frame f = the scene at depth 1+f) so that a mix-up of frames cannot go unnoticed.
+    scene_d = rt_host.load_scene(scene)
+    blobs = []
+    for f in range(world):
+        sc = dict(scene_d)
+        sc["segs"] = 1 + (f % 3)
+        blobs.append(rt_host.flatten_scene(sc))
+    send = torch.zeros((world, plan.band_rows, w, 4), dtype=torch.uint8)
+    for f in range(world):
+        if rows:
+            data = np.frombuffer(ou.c_oracle_rows(blobs[f], w, h, rows), dtype=np.uint8).reshape(len(rows), w, 4)
+            send[f, :len(rows)] = torch.from_numpy(data.copy())
+    recv = torch.empty_like(send)
+    shard.exchange_bands(send, recv, async_op=True).wait()
+    mine = torch.empty((h, w, 4), dtype=torch.uint8)
+    shard.deinterleave(plan, recv, mine)
+    whole = np.frombuffer(ou.c_oracle_render(blobs[rank], w, h), dtype=np.uint8).reshape(h, w, 4)
+    ok2 = torch.tensor([int(np.array_equal(mine.numpy(), whole))])
+    dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("DIST_RESULT_A2A world=%d identical=%d" % (world, int(ok2.item())), flush=True)
+    ok = ok and int(ok2.item())
     t = torch.tensor([ok])
     dist.broadcast(t, src=0)
     dist.barrier()

@@ -255,3 +255,28 @@ def test_enclosing_sphere_shortcut_is_exact(lib, variant):
     blob = rt_host.flatten_scene(s)
     w, h = 160, 90
     assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1
+
+
+def test_batch_launch_equals_per_frame_launches(lib):
+    """rt_render_batch_device: n_frames frames of interleaved tiles in one launch (grid z = frame) write,
+    per frame, exactly what rt_render_tiles_device writes; all three ways of splitting grid y are covered
+    (power-of-two row blocks per tile, a single tile, and the general division)."""
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    w, h = 200, 150
+    for tiles in [(16, 1, 3, 4), (150, 0, 1, 1), (24, 0, 2, 3), (8, 2, 3, 6)]:
+        t = rt_host.RtTiles(*tiles)
+        band = t.n_tiles * t.tile_rows * w * 4
+        single = gpu_tiles(lib, blob, w, h, tiles)
+        n_frames = 3
+        d = lib.rt_alloc_device(0, band * n_frames)
+        try:
+            r = rt_host.Renderer(blob, 0, lib)
+            st = r.render_batch(w, h, d, t, n_frames, band, want_stats=True)
+            host = C.create_string_buffer(band * n_frames)
+            assert lib.rt_copy_to_host(0, host, d, band * n_frames) == 0
+            r.close()
+        finally:
+            lib.rt_free_device(0, d)
+        for f in range(n_frames):
+            assert host.raw[f * band:(f + 1) * band] == single, (tiles, f)
+        assert st.pixels % n_frames == 0

@@ -38,4 +38,5 @@ def test_gather_and_deinterleave_world(world, scene, w, h, tile_rows, built):
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), scene, str(w), str(h), str(tile_rows)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "DIST_RESULT world=%d identical=1" % world in r.stdout
+    assert "DIST_RESULT world=%d identical=1" % world in r.stdout          # gather-to-root form (rt_render's plan)
+    assert "DIST_RESULT_A2A world=%d identical=1" % world in r.stdout      # batch + all-to-all form (bench.py's plan)
