@@ -114,6 +114,11 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
     frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)          # this rank's reassembled frame
+    # N=1: consecutive frames alternate between two HIP streams and two frame buffers, so the tail of frame k
+    # (the last workgroups draining) overlaps the head of frame k+1 instead of idling the chip
+    frame_b = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if world == 1 else None
+    tstream_b = torch.cuda.Stream(device=dev) if world == 1 else None
+    two_streams = world == 1 and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
     if world > 1:
@@ -137,7 +142,10 @@ def main():
 
     def step(k):
         if world == 1:
-            render_step(0)
+            if two_streams and (k & 1):
+                renderer.render_tiles(w, h, frame_b.data_ptr(), whole, stream=tstream_b.cuda_stream, flags=flags)
+            else:
+                render_step(0)
             return
         slot = k & 1
         if len(pending) == 2:                                    # the exchange that last used this slot
@@ -213,7 +221,7 @@ def main():
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
         if world == 1:
-            how = "one launch per frame"
+            how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
         else:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
                    "reassembles frame f on rank f, de-interleave in HBM; exchange of step k overlaps render of step k+1" % (world, TILE_ROWS, world))
