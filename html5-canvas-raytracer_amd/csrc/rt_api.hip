@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -81,6 +82,8 @@ struct rt_scene_dev {
   rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
   rt_geom *d_geom;               // geometry tables, two orderings: [A: plain, camera, lights][B: plain, camera, lights]
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
+  uint8_t *d_lds_image;          // per ordering: [materials | 16 texture descriptors | cull rectangles], the LDS image
+  size_t lds_image_bytes;        // of one ordering
   rt_scene_header hd;            // host copy
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
   unsigned lds_bytes;
@@ -148,6 +151,56 @@ extern "C" int rt_scene_validate(const void *blob, size_t bytes) {
   return RT_OK;
 }
 
+// ------------------------------------------------------------------------------------ primary-ray cull rectangles (host logic)
+// A primary ray has direction (s0*X, s1*Y, s2*D) with s = axisX+axisY+axisZ per component (the reference's
+// component-indexed target formula, main.js:187-191), X = x - w/2 + 0.5, Y = h/2 - y - 0.5, D = projD.
+// For a sphere at C = origin - camera with radius R, the rays with a given X/D = xi all lie in the plane
+// through the camera spanned by (s0*xi, 0, s2) and the y axis; that plane meets the sphere iff the sphere's
+// centre is within R of it:  (C0*s2 - C2*s0*xi)^2 <= R^2 (s2^2 + s0^2 xi^2),  a quadratic in xi whose root
+// interval bounds every pixel column whose LINE meets the sphere (a superset of the columns whose ray hits
+// it).  Same for rows with (C1, s1).  Unbounded or doubtful cases return the whole axis.
+namespace {
+void axis_bounds(double c_axis, double c_z, double s_axis, double s_z, double r2, double *lo, double *hi) {
+  *lo = -INFINITY; *hi = INFINITY;
+  const double A = s_axis * s_axis * (c_z * c_z - r2);
+  const double B = -2.0 * c_axis * c_z * s_axis * s_z;
+  const double Cq = s_z * s_z * (c_axis * c_axis - r2);
+  const double disc = B * B - 4.0 * A * Cq;
+  if (!(A > 1e-12 * s_axis * s_axis * (c_z * c_z + r2)) || !(disc >= 0.0)) return;   // image unbounded along this axis (or degenerate)
+  const double sq = sqrt(disc);
+  const double x1 = (-B - sq) / (2.0 * A), x2 = (-B + sq) / (2.0 * A);
+  if (!(x1 <= x2) || !std::isfinite(x1) || !std::isfinite(x2)) return;
+  *lo = x1 - 1e-7 * (1.0 + fabs(x1));                 // margins far above rounding, far below a pixel (1/D >= 1.5e-5)
+  *hi = x2 + 1e-7 * (1.0 + fabs(x2));
+}
+
+rt_geom cull_rect(const rt_scene_header *hd, const rt_sphere &o) {
+  rt_geom r = {-INFINITY, INFINITY, -INFINITY, INFINITY};          // {x_lo, x_hi, y_lo, y_hi}
+  const double c[3] = {o.origin[0] - hd->cam_origin[0], o.origin[1] - hd->cam_origin[1], o.origin[2] - hd->cam_origin[2]};
+  const double s[3] = {hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
+                       hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2]};
+  const double k = (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) - o.r2;
+  if (!(k > 1e-9 * o.r2) || !(o.r2 > 0.0)) return r;              // camera inside / on / near the sphere: no bound
+  axis_bounds(c[0], c[2], s[0], s[2], o.r2, &r.ox, &r.oy);
+  axis_bounds(c[1], c[2], s[1], s[2], o.r2, &r.oz, &r.r2);
+  return r;
+}
+}  // namespace
+
+// Host-logic probe for tests: the cull rectangle of every sphere, scene order, 4 doubles each.
+extern "C" int rt_scene_cull_rects(const void *blob, size_t bytes, double *out) {
+  int rc = rt_scene_validate(blob, bytes);
+  if (rc) return rc;
+  if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+  const rt_scene_header *hd = (const rt_scene_header *)blob;
+  const rt_sphere *ob = (const rt_sphere *)((const uint8_t *)blob + hd->objects_offset);
+  for (uint32_t i = 0; i < hd->n_objects; i++) {
+    const rt_geom r = cull_rect(hd, ob[i]);
+    out[4 * i] = r.ox; out[4 * i + 1] = r.oy; out[4 * i + 2] = r.oz; out[4 * i + 3] = r.r2;
+  }
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------ upload
 extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
   if (!out) return fail(RT_ERR_INVALID, "out handle is NULL");
@@ -157,12 +210,12 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if ((rc = ensure_device(device))) return rc;
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
-  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr;
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
   for (uint32_t i = 0; i < hd->n_objects; i++) if (ob[i].albedo[4] > 0.0) s->refract = true;
-  s->lds_bytes = hd->n_objects * (unsigned)sizeof(rt_sphere) + RT_MAX_TEXTURES * (unsigned)sizeof(rt_texture_desc);
+  s->lds_bytes = hd->n_objects * (unsigned)(sizeof(rt_sphere) + sizeof(rt_geom)) + RT_MAX_TEXTURES * (unsigned)sizeof(rt_texture_desc);
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
   rt_texture_desc descs[RT_MAX_TEXTURES];
@@ -187,11 +240,11 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     for (uint32_t i = 0; i < hd->n_objects; i++) pob[i].reserved = 1.0 / sqrt(pob[i].r2);
   }
   // Geometry tables (32-byte records), per ordering: [0,N) plain {origin, r2}; [N,2N) anchored at the camera
-  // {o - cam, |o - cam|^2 - r2}; [2N, 2N + NL*N) anchored at each light.  Ordering A = the scene's own order
+  // {o - cam, |o - cam|^2 - r2}; [2N,3N) primary-ray cull rectangles; [3N, 3N + NL*N) anchored at each light.  Ordering A = the scene's own order
   // (strict kernel, counting variant).  Ordering B = the enclosing sphere moved to the end, so the product
   // kernel's loops run over [0, N-1) and never test it.
   const uint32_t NO = hd->n_objects;
-  const size_t per_order = (size_t)NO * (2 + hd->n_lights);
+  const size_t per_order = (size_t)NO * (3 + hd->n_lights);
   const bool has_b = s->enclosing != ~0u;
   std::vector<rt_geom> geom(per_order * (has_b ? 2 : 1));
   std::vector<rt_sphere> objs_b;
@@ -203,7 +256,8 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     for (uint32_t i = 0; i < NO; i++) {
       dst[i] = rt_geom{src[i].origin[0], src[i].origin[1], src[i].origin[2], src[i].r2};
       dst[NO + i] = anchored(src[i], hd->cam_origin);
-      for (uint32_t k = 0; k < hd->n_lights; k++) dst[(size_t)NO * (2 + k) + i] = anchored(src[i], s->lights[k]);
+      dst[2 * (size_t)NO + i] = cull_rect(hd, src[i]);
+      for (uint32_t k = 0; k < hd->n_lights; k++) dst[(size_t)NO * (3 + k) + i] = anchored(src[i], s->lights[k]);
     }
   };
   const rt_sphere *pob_a = (const rt_sphere *)(patched.data() + hd->objects_offset);
@@ -217,6 +271,19 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
   if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
+  {
+    // the LDS image, per ordering
+    s->lds_image_bytes = (size_t)NO * (sizeof(rt_sphere) + sizeof(rt_geom)) + sizeof descs;
+    std::vector<uint8_t> img(s->lds_image_bytes * (has_b ? 2 : 1));
+    for (int ord = 0; ord < (has_b ? 2 : 1); ord++) {
+      uint8_t *dst = img.data() + ord * s->lds_image_bytes;
+      memcpy(dst, ord ? (const void *)objs_b.data() : (const void *)pob_a, (size_t)NO * sizeof(rt_sphere));
+      memcpy(dst + (size_t)NO * sizeof(rt_sphere), descs, sizeof descs);
+      memcpy(dst + (size_t)NO * sizeof(rt_sphere) + sizeof descs, geom.data() + ord * per_order + 2 * (size_t)NO, (size_t)NO * sizeof(rt_geom));
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_lds_image, img.size());
+    if (e == hipSuccess) e = hipMemcpy(s->d_lds_image, img.data(), img.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && has_b) e = hipMalloc((void **)&s->d_objects_b, objs_b.size() * sizeof(rt_sphere));
   if (e == hipSuccess && has_b) e = hipMemcpy(s->d_objects_b, objs_b.data(), objs_b.size() * sizeof(rt_sphere), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_blob, patched.data(), bytes, hipMemcpyHostToDevice);
@@ -226,6 +293,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     if (s->d_texdesc) (void)hipFree(s->d_texdesc);
     if (s->d_geom) (void)hipFree(s->d_geom);
     if (s->d_objects_b) (void)hipFree(s->d_objects_b);
+    if (s->d_lds_image) (void)hipFree(s->d_lds_image);
     delete s;
     return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
   }
@@ -240,6 +308,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   (void)hipFree(s->d_texdesc);
   (void)hipFree(s->d_geom);
   if (s->d_objects_b) (void)hipFree(s->d_objects_b);
+  if (s->d_lds_image) (void)hipFree(s->d_lds_image);
   delete s;
 }
 
@@ -271,12 +340,14 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   // ordering B (enclosing sphere last, outside the loops) for the product kernel; the strict kernel and the
   // counting variant walk the scene in its own order so that they stay literal / count what the reference counts
   const bool order_b = s->d_objects_b && !(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT));
-  const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (2 + hd.n_lights) : 0);
+  const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (3 + hd.n_lights) : 0);
   L.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
   L.textures = s->d_texdesc;
   L.geom = gt;
   L.geom_cam = gt + hd.n_objects;
-  L.geom_light = gt + 2 * (size_t)hd.n_objects;
+  L.cull = gt + 2 * (size_t)hd.n_objects;
+  L.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
+  L.geom_light = gt + 3 * (size_t)hd.n_objects;
   L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
   L.enclosing = order_b ? hd.n_objects - 1 : ~0u;
   L.texel_base = db;

@@ -23,6 +23,8 @@ struct rt_launch {
   const rt_sphere *objects;          // n_objects records of 192 B (materials; staged into LDS per workgroup)
   const rt_geom *geom;               // n_objects compact geometry records for the scalar-loaded loops
   const rt_geom *geom_cam;           // anchored at the camera: {o - cam, |o - cam|^2 - r2} per sphere
+  const void *lds_image;             // [materials (n_objects x 192 B) | 16 texture descriptors | cull rectangles]: the workgroup's LDS image
+  const rt_geom *cull;               // per sphere {x_lo, x_hi, y_lo, y_hi}: bounds of X/D, Y/D of the pixels whose line meets it
   const rt_geom *geom_light;         // anchored at light k: [k*n_objects + j] = {o_j - light_k, |o_j - light_k|^2 - r2_j}
   const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`
   const uint8_t *texel_base;

@@ -202,7 +202,9 @@ template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3
 
 template <bool REFRACT, bool COUNT>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
-                                            [[maybe_unused]] double *acc, v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
+                                            [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
+                                            [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
+                                            [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
   const sphere_kptr objs = (sphere_kptr)L.objects;
   const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
@@ -222,16 +224,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   uint32_t segs_left = L.segs;
 #endif
   double ret[3] = {0.0, 0.0, 0.0};
-  [[maybe_unused]] bool primary = true;                 // the first node evaluated is the primary ray (origin = camera, uniform)
 
-  if (segs_left != 0) {
-    for (;;) {
-      // ---------------- evaluate one intersectWorld node (segs_left > 0 here) ----------------
-      if (COUNT) cnt[0]++;
-      // A3: closest hit.  Uniform trip count, sphere geometry via scalar loads.
-      // The winner is kept as one int, 2*i + inside, so a candidate costs one 64-bit and one
-      // 32-bit select.
-      double ht = RT_INF; int hcode = -1;
+  // A3: closest hit.  The winner is kept as (ht, hcode) with hcode = 2*index + inside, so a candidate costs one
+  // 64-bit and one 32-bit select.
+  double ht = RT_INF; int hcode = -1;
       // One candidate: the sqrt and the bookkeeping stay inside the hit branch (RT_PIN).
 #define RT_CAND(IDX, TCA, DISC)                                                               \
       if (!((DISC) < 0.0)) {                                                                  \
@@ -263,17 +259,38 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
       // the compiler's runtime unrolling); the two s_load_dwordx8 of a pair are issued together.
 #if !RT_STRICT
-      if (level == 0 && primary) {
+  if (segs_left != 0) {
+        // Primary rays.  First a wave-wide cull: lane j compares sphere j's conservative screen rectangle
+        // (host, resolution-independent: bounds of X/D and Y/D over the pixels whose LINE meets the sphere)
+        // with the rectangle of this wave's 8x8 pixel block; __ballot turns the 64 verdicts into one scalar
+        // mask and only the surviving spheres are tested, in index order (the tie-break is preserved).
+        // A wave of sky pixels tests nothing; a wave of floor pixels tests the floor.
         const geom_kptr ga = (geom_kptr)L.geom_cam;
-        uint32_t i = 0;
-        for (; i + 2 <= NLOOP; i += 2) {
-          const rt_geom g0 = RT_LOAD(ga, i), g1 = RT_LOAD(ga, i + 1);
-          RT_ANCHORED(i, g0) RT_ANCHORED(i + 1, g1)
+        for (uint32_t base = 0; base < NLOOP; base += 64u) {
+          const uint32_t j = base + lane;
+          const rt_geom cr = cull[j < NLOOP ? j : 0u];                   // LDS: {x_lo, x_hi, y_lo, y_hi} in units of 1/D
+          const bool keep = (j < NLOOP) && (cr.ox * L.proj_d <= blk_x1) && (cr.oy * L.proj_d >= blk_x0) &&
+                            (cr.oz * L.proj_d <= blk_y1) && (cr.r2 * L.proj_d >= blk_y0);
+          unsigned long long m = __ballot(keep);
+          while (m) {
+            const uint32_t i = base + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const rt_geom g0 = RT_LOAD(ga, i);
+            RT_ANCHORED(i, g0)
+          }
         }
-        if (i < NLOOP) { const rt_geom g0 = RT_LOAD(ga, i); RT_ANCHORED(i, g0) }
-      } else
+  }
+  bool searched = true;                // the primary ray's candidates were found above (camera-anchored, culled)
+#else
+  bool searched = false;
 #endif
-      {
+
+  if (segs_left != 0) {
+    for (;;) {
+      // ---------------- evaluate one intersectWorld node (segs_left > 0 here) ----------------
+      if (COUNT) cnt[0]++;
+      if (!searched) {                              // reflection / refraction rays: any origin, generic form
+        ht = RT_INF; hcode = -1;
         uint32_t i = 0;
         for (; i + 2 <= NLOOP; i += 2) {
           const rt_geom g0 = RT_LOAD(geom, i), g1 = RT_LOAD(geom, i + 1);
@@ -281,6 +298,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         }
         if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
       }
+      searched = false;
       // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) is
       // kept LAST in the device tables and outside the loops above: it can only be the closest hit of a
       // ray that hits nothing else.  Only the lanes still without a hit evaluate it.
@@ -291,7 +309,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #undef RT_ANCHORED
 #undef RT_GENERIC
 #undef RT_CAND
-      primary = false;
       if (COUNT) cnt[2] += N;
       const int hi = hcode >> 1;
       const bool inside = (hcode & 1) != 0;
@@ -576,16 +593,20 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 template <bool REFRACT, bool COUNT, bool SS2>
 __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const rt_launch L) {
   extern __shared__ double lds_raw[];
-  // ---- stage the material table and the texture descriptors into LDS (once per workgroup) ----
+  // ---- stage the per-workgroup tables into LDS: ONE contiguous image in HBM (materials | texture descriptors |
+  //      cull rectangles, laid out exactly as the LDS copy), so a workgroup pays one memory latency, not three;
+  //      the loads are issued first and land while the ray is being generated ----
   const uint32_t tid = threadIdx.x;
   const uint32_t mtl_words = L.n_objects * (uint32_t)(sizeof(rt_sphere) / 8);
   const uint32_t tex_words = 16u * 2u;               // RT_MAX_TEXTURES descriptors of 16 B
-  for (uint32_t k = tid; k < mtl_words; k += RT_WG_THREADS) lds_raw[k] = ((const double *)L.objects)[k];
-  for (uint32_t k = tid; k < tex_words; k += RT_WG_THREADS) lds_raw[mtl_words + k] = ((const double *)L.textures)[k];
-  __syncthreads();
+  const uint32_t cull_words = L.n_objects * 4u;       // per-sphere screen rectangles for the primary-ray cull
+  const uint32_t image_words = mtl_words + tex_words + cull_words;
+  const double *__restrict__ image = (const double *)L.lds_image;
+  const double stage0 = (tid < image_words) ? image[tid] : 0.0;                   // 8 spheres: exactly one word per work-item
   const rt_sphere *mtl = (const rt_sphere *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
-  double *acc = lds_raw + mtl_words + tex_words + tid;   // 10 x RT_WG_THREADS doubles, lane-major (product chain kernel only)
+  const rt_geom *cull = (const rt_geom *)(lds_raw + mtl_words + tex_words);
+  double *acc = lds_raw + mtl_words + tex_words + cull_words + tid;   // 10 x RT_WG_THREADS doubles, lane-major (product chain kernel only)
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t wave = tid >> 6, lane = tid & 63u;
@@ -622,7 +643,17 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
 
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
-  trace_pixel<REFRACT, COUNT>(L, mtl, tex, acc, o, ray, rgb, cnt);
+  // finish the staging (first use of LDS is the cull table inside trace_pixel)
+  if (tid < image_words) lds_raw[tid] = stage0;
+  for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
+  __syncthreads();
+
+  // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)
+  const double bw = SS2 ? 15.0 : 7.0, bh = SS2 ? 3.0 : 7.0;
+  const double lx = SS2 ? (double)(2u * ((lane >> 2) & 7u) + (sub & 1u)) : (double)(lane & 7u);
+  const double ly = SS2 ? (double)(2u * (lane >> 5) + (sub >> 1)) : (double)(lane >> 3);
+  const double blk_x0 = d0 - lx, blk_x1 = blk_x0 + bw, blk_y1 = d1 + ly, blk_y0 = blk_y1 - bh;
+  trace_pixel<REFRACT, COUNT>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
 
   // ---- A10 RGBA8 store ----
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);

@@ -139,6 +139,7 @@ ABI = {
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
     "rt_scene_validate": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_scene_cull_rects": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
     "rt_scene_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_scene_free": (None, [C.c_void_p]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_void_p, C.c_void_p,

@@ -137,6 +137,11 @@ uint32_t rt_abi_version(void);
 /* Validate a scene blob without touching a GPU (host logic; usable in CPU-only tests). */
 int rt_scene_validate(const void *scene_blob, size_t blob_bytes);
 
+/* Host-logic probe (no GPU): the conservative screen rectangle the product kernel uses to cull spheres for
+ * primary rays, per sphere in scene order: {x_lo, x_hi, y_lo, y_hi} bounding X/D and Y/D of every pixel whose
+ * line meets the sphere (X = x - w/2 + 0.5, Y = h/2 - y - 0.5, D = (w/2)/tan(fov/2); +-inf = unbounded). */
+int rt_scene_cull_rects(const void *scene_blob, size_t blob_bytes, double *out_4n);
+
 /* Upload a scene to `device` (index into the GPUs in use) and keep it resident. */
 int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_scene_dev **out);
 void rt_scene_free(rt_scene_dev *scene);

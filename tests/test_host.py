@@ -139,3 +139,52 @@ def test_png_decoder_matches_pil_on_reference_textures():
         pil = np.asarray(Image.open(os.path.join(ou.REFERENCE_DIR, n + ".png")).convert("RGBA")).tobytes()
         ours = open(os.path.join(ou.SCENES, n + "_256x128.rgba"), "rb").read()
         assert pil == ours
+
+
+def test_cull_rectangles_are_conservative(built):
+    """Host logic of the product kernel's primary-ray cull (rt_scene_cull_rects): for random spheres and the
+    reference camera, every pixel whose primary ray hits the sphere (and every pixel whose LINE meets it) lies
+    inside the rectangle; spheres around the camera are unbounded."""
+    import math
+    import random
+    import numpy as np
+    lib = rt_host.load_library()
+    rng = random.Random(7)
+    scene = rt_host.load_scene("h8")
+    base = scene["objects"][0]
+    objs = []
+    for _ in range(60):
+        r = rng.choice([0.05, 0.3, 1.0, 4.0, 30.0, 500.0])
+        o = dict(base)
+        o["origin"] = [rng.uniform(-60, 60), rng.uniform(-40, 40), rng.uniform(-120, 30)]
+        o["r2"] = r * r
+        objs.append(o)
+    scene["objects"] = objs
+    blob = rt_host.flatten_scene(scene)
+    buf = C.create_string_buffer(blob, len(blob))
+    out = (C.c_double * (4 * len(objs)))()
+    assert lib.rt_scene_cull_rects(buf, len(blob), out) == 0, lib.rt_last_error()
+    rects = np.array(out).reshape(-1, 4)
+    w, h = 160, 90
+    D = (w / 2) / math.tan(math.radians(scene["fovDeg"]) / 2)
+    cam = np.array(scene["camera"]["origin"])
+    s = np.array(scene["camera"]["axisX"]) + np.array(scene["camera"]["axisY"]) + np.array(scene["camera"]["axisZ"])
+    X = (np.arange(w) - w / 2 + 0.5)[None, :].repeat(h, 0)
+    Y = (h / 2 - np.arange(h) - 0.5)[:, None].repeat(w, 1)
+    ray = np.stack([s[0] * X, s[1] * Y, np.full_like(X, s[2] * D)], -1)
+    ray /= np.linalg.norm(ray, axis=-1, keepdims=True)
+    bounded = 0
+    for o, (x0, x1, y0, y1) in zip(objs, rects):
+        c = np.array(o["origin"]) - cam
+        tca = ray @ c
+        d2 = c @ c - tca * tca
+        line_meets = d2 <= o["r2"]
+        inside = (X / D >= x0) & (X / D <= x1) & (Y / D >= y0) & (Y / D <= y1)
+        assert not (line_meets & ~inside).any(), (o["origin"], o["r2"], (x0, x1, y0, y1))
+        if c @ c <= o["r2"]:
+            assert math.isinf(x0) and math.isinf(x1) and math.isinf(y0) and math.isinf(y1)
+        bounded += int(math.isfinite(x0) and math.isfinite(y0))
+        if math.isfinite(x0) and x0 > X[0, 0] / D and x1 < X[0, -1] / D and line_meets.any():   # tight when the image is inside the frame
+            cols = np.where(line_meets.any(0))[0]
+            assert (X[0, cols[0]] / D - x0) * D < 1.5 and (x1 - X[0, cols[-1]] / D) * D < 1.5
+    assert bounded > 20
