@@ -410,13 +410,47 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
 }
 
 // ------------------------------------------------------------------------------------ memory helpers
+// Pinned framebuffers are recycled: hipHostMalloc of a 33 MB frame costs ~15 ms, ten times the render.
+// A freed buffer goes to a small pool (same-size reuse); at most 4 buffers / 1 GiB are kept.
+namespace {
+struct pinned_buf { void *p; size_t bytes; };
+std::mutex g_pin_mu;
+std::vector<pinned_buf> g_pin_live, g_pin_free;
+}  // namespace
+
 extern "C" void *rt_alloc_pinned(size_t bytes) {
+  if (!bytes) bytes = 1;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pin_free.size(); i++)
+      if (g_pin_free[i].bytes == bytes) {
+        pinned_buf b = g_pin_free[i];
+        g_pin_free.erase(g_pin_free.begin() + i);
+        g_pin_live.push_back(b);
+        return b.p;
+      }
+  }
   void *p = nullptr;
-  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
   if (e != hipSuccess) { fail(RT_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pin_live.push_back({p, bytes});
   return p;
 }
-extern "C" void rt_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" void rt_free_pinned(void *p) {
+  if (!p) return;
+  pinned_buf b = {p, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pin_live.size(); i++)
+      if (g_pin_live[i].p == p) { b = g_pin_live[i]; g_pin_live.erase(g_pin_live.begin() + i); break; }
+    size_t pooled = 0;
+    for (const pinned_buf &f : g_pin_free) pooled += f.bytes;
+    if (b.bytes && g_pin_free.size() < 4 && pooled + b.bytes <= ((size_t)1 << 30)) { g_pin_free.push_back(b); return; }
+  }
+  (void)hipHostFree(p);
+}
 
 extern "C" void *rt_alloc_device(int device, size_t bytes) {
   if (ensure_device(device)) return nullptr;
@@ -611,6 +645,11 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
 }
 
 extern "C" void rt_shutdown(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const pinned_buf &f : g_pin_free) (void)hipHostFree(f.p);
+    g_pin_free.clear();
+  }
   std::lock_guard<std::mutex> lk(G.mu);
   if (!G.inited) return;
   if (G.comms_ready) { for (size_t g = 0; g < G.dev.size(); g++) if (G.comms[g]) NCCL.destroy(G.comms[g]); G.comms_ready = false; }
