@@ -46,3 +46,31 @@ def test_node_render_matches_reference_frames(built):
     assert out["constructed"] <= 1 and out["async"] <= 1
     assert out["counted"]["pixels"] == 240 * 135 and out["counted"]["rays"] > out["counted"]["pixels"]
     assert "sampler" in out["unsupported"]
+
+
+def _run_server_check():
+    r = subprocess.run([ou.node_path(), os.path.join(ROOT, "tests", "js_server_check.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@needs_node
+def test_http_bridge_surface(built):
+    """the page shell + /frame bridge.  Without a GPU /frame is a 503 with the library's error —
+    never a CPU-rendered frame."""
+    out = _run_server_check()
+    assert out["page"] == {"status": 200, "canvas": True, "putImageData": True}
+    assert "h8" in out["scenes"] and "default14" in out["scenes"]
+    assert out["bad"] == [400, 404, 400, 404]
+    import torch
+    if not torch.cuda.is_available():
+        assert out["frame"]["status"] == 503 and "no HIP device" in out["frame"]["error"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_http_bridge_serves_reference_frame(built):
+    out = _run_server_check()
+    assert out["frame"]["status"] == 200 and out["frame"]["bytes"] == 240 * 135 * 4
+    assert out["frame"]["diff"] <= 1 and float(out["frame"]["kernelMs"]) > 0
