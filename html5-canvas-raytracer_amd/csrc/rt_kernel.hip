@@ -83,11 +83,15 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
   return v;
 }
 #else
+// Measured on MI355X (build/probe/prec.hip, 1M random inputs over 1e-6..1e8): v_rsq_f64 / v_rcp_f64 are good to
+// 2^-24; one Newton step gives 4.1e-15 / 2.1e-15, two give 1.4e-16 / 1.1e-16; x*rsqrt(x) after ONE step plus
+// the residual correction g += (x - g*g) * y/2 is a square root good to 1.1e-16.
+// rt_rsqrt_pos is only ever used to NORMALISE a vector.  An error in the scale of a direction moves no hit
+// point (p + d*t is invariant under rescaling d) and no reflection direction; it reaches only continuous
+// quantities (a cosine, a distance) at the 4e-15 level, so one Newton step is enough there.
 __device__ __forceinline__ double rt_rsqrt_pos(double m) {           // m > 0, finite
-  double y = __builtin_amdgcn_rsq(m);
-  double e = __builtin_fma(-(m * y), y, 1.0);
-  y = __builtin_fma(0.5 * y, e, y);
-  e = __builtin_fma(-(m * y), y, 1.0);
+  const double y = __builtin_amdgcn_rsq(m);
+  const double e = __builtin_fma(-(m * y), y, 1.0);
   return __builtin_fma(0.5 * y, e, y);
 }
 __device__ __forceinline__ double rt_sqrt(double x) {
@@ -100,9 +104,7 @@ __device__ __forceinline__ double rt_sqrt(double x) {
 // selecting afterwards: 0 * 1e100 = 0 through every step below.
 __device__ __forceinline__ double rt_sqrt_nn(double x) {
   double y = __builtin_fmin(__builtin_amdgcn_rsq(x), 1e100);
-  double e = __builtin_fma(-(x * y), y, 1.0);
-  y = __builtin_fma(0.5 * y, e, y);
-  e = __builtin_fma(-(x * y), y, 1.0);
+  const double e = __builtin_fma(-(x * y), y, 1.0);
   y = __builtin_fma(0.5 * y, e, y);
   const double g = x * y;
   return __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
