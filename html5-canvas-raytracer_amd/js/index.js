@@ -24,7 +24,8 @@ function native() {
 
 const FLAG_COUNT = 1, FLAG_STRICT_FP = 2;
 let inited = false;
-function init(maxDevices) { const n = native().init(maxDevices || 0); inited = true; return n; }
+// maxDevices: GPUs rt_render may shard one frame over (RCCL gather); default 1.  Pass 0 for every visible GPU.
+function init(maxDevices) { const n = native().init(maxDevices === undefined ? 1 : maxDevices); inited = true; return n; }
 function flagsOf(opts) { return ((opts && opts.count) ? FLAG_COUNT : 0) | ((opts && opts.strictFp) ? FLAG_STRICT_FP : 0); }
 
 // -> Uint8ClampedArray of length 4*width*height over a pinned host buffer; `.stats` carries timings

@@ -231,11 +231,12 @@ class Renderer:
             pass
 
 
-def render(width, height, scene, flags=0, lib=None):
-    """render(width,height,scene) -> (bytes RGBA8, RtStats): the whole-frame entry point, host buffer out."""
+def render(width, height, scene, flags=0, lib=None, max_devices=1):
+    """render(width,height,scene) -> (bytes RGBA8, RtStats): the whole-frame entry point, host buffer out.
+    max_devices > 1 (or 0 = all) lets rt_render shard the frame over the node's GPUs (RCCL gather)."""
     lib = lib or load_library()
     blob = scene if isinstance(scene, (bytes, bytearray)) else flatten_scene(scene)
-    _check(lib, lib.rt_init(0), "rt_init")
+    _check(lib, lib.rt_init(max_devices), "rt_init")
     n = width * height * 4
     p = lib.rt_alloc_pinned(n)
     if not p:
