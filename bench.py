@@ -127,6 +127,10 @@ def main():
         recv = [torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
         host_recv = torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8) if rehearse else None
     pending = []      # (work, slot) of exchanges in flight; at most 2
+    # the wait for an exchange and the de-interleave that follows run on a SIDE stream, so the render stream
+    # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    slot_free = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
 
     def render_step(slot):
         if world == 1:
@@ -136,10 +140,13 @@ def main():
 
     def finish(slot_work):
         work, slot = slot_work
-        work.wait()                                              # current stream waits for the exchange
-        if rehearse:
-            recv[slot].copy_(host_recv)
-        shard.deinterleave(plan, recv[slot], frame, lib=lib, device_index=dev_index, stream=stream)
+        with torch.cuda.stream(side):
+            work.wait()                                          # the side stream waits for the exchange
+            if rehearse:
+                recv[slot].copy_(host_recv)
+            shard.deinterleave(plan, recv[slot], frame, lib=lib, device_index=dev_index, stream=side.cuda_stream)
+            slot_free[slot].record(side)
+        tstream.wait_event(slot_free[slot])                      # ordering only: that work is two steps old by the time it matters
 
     def step(k):
         if world == 1:

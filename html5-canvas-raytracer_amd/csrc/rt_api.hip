@@ -473,29 +473,35 @@ extern "C" int rt_copy_to_host(int device, void *dst, const void *src, size_t by
 
 // ------------------------------------------------------------------------------------ de-interleave
 // src: for rank g, its tiles (g, g+R, g+2R, ...) stored contiguously, ranks `rank_stride` bytes apart.
-// dst: the frame in row order.  One work-item moves 16 bytes; rows are w*4 bytes (w % 4 == 0 fast path).
-__global__ void __launch_bounds__(256) rt_deinterleave_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t w, uint32_t h,
-                                                              uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_words) {
-  const uint64_t total = (uint64_t)w * h;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t row = (uint32_t)(i / w), x = (uint32_t)(i - (uint64_t)row * w);
-    const uint32_t tile = row / tile_rows, r = row - tile * tile_rows;
-    const uint32_t rank = tile % n_ranks, local_tile = tile / n_ranks;
-    dst[i] = src[rank * rank_stride_words + ((uint64_t)local_tile * tile_rows + r) * w + x];
-  }
+// dst: the frame in row order.  One workgroup row per frame row (grid y), so the tile/rank arithmetic is
+// wave-uniform scalar work done once; a work-item moves 16 bytes (T = uint4) or, for ragged widths, 4 (T = uint32_t).
+template <typename T>
+__global__ void __launch_bounds__(256) rt_deinterleave_kernel(const T *__restrict__ src, T *__restrict__ dst, uint32_t row_elems, uint32_t tile_rows,
+                                                              uint32_t n_ranks, uint64_t rank_stride_elems) {
+  const uint32_t row = blockIdx.y;
+  const uint32_t tile = row / tile_rows, r = row - tile * tile_rows;
+  const uint32_t rank = tile % n_ranks, local_tile = tile / n_ranks;
+  const T *__restrict__ s = src + rank * rank_stride_elems + ((uint64_t)local_tile * tile_rows + r) * row_elems;
+  T *__restrict__ d = dst + (uint64_t)row * row_elems;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < row_elems; x += gridDim.x * blockDim.x) d[x] = s[x];
 }
 
 extern "C" int rt_deinterleave_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h, uint32_t tile_rows, uint32_t n_ranks,
                                       uint64_t rank_stride_bytes, void *hip_stream) {
-  if (!d_src || !d_dst || !w || !h || !tile_rows || !n_ranks || (rank_stride_bytes & 3u)) return fail(RT_ERR_INVALID, "bad de-interleave arguments");
+  if (!d_src || !d_dst || !w || !h || !tile_rows || !n_ranks || (rank_stride_bytes & 3u) || h > 65535u * 16u) return fail(RT_ERR_INVALID, "bad de-interleave arguments");
   int rc = ensure_device(device);
   if (rc) return rc;
   hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[device].stream;
-  const uint64_t total = (uint64_t)w * h;
-  unsigned blocks = (unsigned)((total + 255) / 256);
-  if (blocks > 256u * 16u) blocks = 256u * 16u;
-  hipLaunchKernelGGL(rt_deinterleave_kernel, dim3(blocks), dim3(256), 0, stream, (const uint32_t *)d_src, (uint32_t *)d_dst, w, h, tile_rows, n_ranks,
-                     rank_stride_bytes / 4u);
+  if (h > 65535u) return fail(RT_ERR_INVALID, "de-interleave: more than 65535 rows");
+  const bool wide = (w % 4u == 0) && (rank_stride_bytes % 16u == 0) && (((uintptr_t)d_src | (uintptr_t)d_dst) % 16u == 0);
+  const uint32_t row_elems = wide ? w / 4u : w;
+  const dim3 grid((row_elems + 255u) / 256u, h), block(256);
+  if (wide)
+    hipLaunchKernelGGL(rt_deinterleave_kernel<uint4>, grid, block, 0, stream, (const uint4 *)d_src, (uint4 *)d_dst, row_elems, tile_rows, n_ranks,
+                       rank_stride_bytes / 16u);
+  else
+    hipLaunchKernelGGL(rt_deinterleave_kernel<uint32_t>, grid, block, 0, stream, (const uint32_t *)d_src, (uint32_t *)d_dst, row_elems, tile_rows,
+                       n_ranks, rank_stride_bytes / 4u);
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }

@@ -287,3 +287,27 @@ def test_batch_launch_equals_per_frame_launches(lib):
             got = np.frombuffer(host.raw[f * band:(f + 1) * band], dtype=np.uint8).reshape(-1, w * 4)[valid]
             assert np.array_equal(got, want), (tiles, f)
         assert st.pixels == int(valid.sum()) * w * n_frames
+
+
+def test_deinterleave_kernel_wide_and_ragged(lib):
+    """rt_deinterleave_device: 16-byte path (w % 4 == 0) and the 4-byte path for ragged widths, against numpy."""
+    rng = np.random.default_rng(3)
+    for w, h, tile_rows, G in [(64, 50, 16, 3), (37, 41, 8, 2), (128, 16, 16, 8), (4, 5, 1, 4)]:
+        n_tiles = (h + tile_rows - 1) // tile_rows
+        per_rank = (n_tiles + G - 1) // G
+        band_rows = per_rank * tile_rows
+        src = rng.integers(0, 256, size=(G, band_rows, w, 4), dtype=np.uint8)
+        want = src.reshape(G, per_rank, tile_rows, w, 4).transpose(1, 0, 2, 3, 4).reshape(-1, w, 4)[:h]
+        d_src = lib.rt_alloc_device(0, src.nbytes)
+        d_dst = lib.rt_alloc_device(0, w * h * 4)
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(d_src), src.ctypes.data_as(C.c_void_p), C.c_size_t(src.nbytes), 1) == 0
+            assert lib.rt_deinterleave_device(0, d_src, d_dst, w, h, tile_rows, G, band_rows * w * 4, None) == 0, lib.rt_last_error()
+            host = C.create_string_buffer(w * h * 4)
+            assert lib.rt_copy_to_host(0, host, d_dst, w * h * 4) == 0
+        finally:
+            lib.rt_free_device(0, d_src)
+            lib.rt_free_device(0, d_dst)
+        assert np.array_equal(np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4), want), (w, h, tile_rows, G)
