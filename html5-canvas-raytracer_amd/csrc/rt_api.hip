@@ -82,6 +82,7 @@ struct rt_scene_dev {
   rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
   rt_geom *d_geom;               // geometry tables, two orderings: [A: plain, camera, lights][B: plain, camera, lights]
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
+  uint64_t *d_shadow_grid;       // light grids for the product kernel's loop order, or NULL (few spheres)
   uint8_t *d_lds_image;          // per ordering: [materials | 16 texture descriptors | cull rectangles], the LDS image
   size_t lds_image_bytes;        // of one ordering
   rt_scene_header hd;            // host copy
@@ -187,6 +188,77 @@ rt_geom cull_rect(const rt_scene_header *hd, const rt_sphere &o) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------ shadow grids (host logic)
+// Buffer layout (all 8-byte units): NL headers of 16 doubles {frame rows x'[3], y'[3], z'[3], gx0, gy0, 1/cell_w,
+// 1/cell_h, pad[3]}, then per light (RT_SGRID*RT_SGRID + 1) cells of `words` uint64 each: bit j of a cell = sphere j
+// (loop order) may block a shadow ray whose hit point projects into that cell; the last cell holds every sphere and
+// serves hit points behind the light's frame plane.  Border cells stand for the half-lines beyond the grid.
+namespace {
+std::vector<uint64_t> build_shadow_grid(const rt_sphere *objs, uint32_t n_loop, uint32_t n_lights, const double lights[][3]) {
+  const uint32_t G = RT_SGRID, words = (n_loop + 63u) / 64u, cells = G * G + 1u;
+  std::vector<uint64_t> buf((size_t)n_lights * 16u + (size_t)n_lights * cells * words, 0ull);
+  double *hdr = (double *)buf.data();
+  uint64_t *masks = buf.data() + (size_t)n_lights * 16u;
+  for (uint32_t k = 0; k < n_lights; k++) {
+    const double *Lp = lights[k];
+    // frame: z' looks from the light at the centroid of the sphere centres
+    double cz[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < n_loop; j++) for (int c = 0; c < 3; c++) cz[c] += (objs[j].origin[c] - Lp[c]) / n_loop;
+    double len = sqrt(cz[0] * cz[0] + cz[1] * cz[1] + cz[2] * cz[2]);
+    double z[3] = {0, -1, 0};
+    if (len > 1e-9 && std::isfinite(len)) for (int c = 0; c < 3; c++) z[c] = cz[c] / len;
+    const double up[3] = {fabs(z[1]) < 0.9 ? 0.0 : 1.0, fabs(z[1]) < 0.9 ? 1.0 : 0.0, 0.0};
+    double x[3] = {up[1] * z[2] - up[2] * z[1], up[2] * z[0] - up[0] * z[2], up[0] * z[1] - up[1] * z[0]};
+    len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    for (int c = 0; c < 3; c++) x[c] /= len;
+    const double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    // per-sphere rectangles in (x'/z', y'/z')
+    std::vector<rt_geom> rect(n_loop);
+    std::vector<char> skip(n_loop, 0);
+    double gx0 = INFINITY, gx1 = -INFINITY, gy0 = INFINITY, gy1 = -INFINITY;
+    for (uint32_t j = 0; j < n_loop; j++) {
+      const double c[3] = {objs[j].origin[0] - Lp[0], objs[j].origin[1] - Lp[1], objs[j].origin[2] - Lp[2]};
+      const double cx = x[0] * c[0] + x[1] * c[1] + x[2] * c[2], cy = y[0] * c[0] + y[1] * c[1] + y[2] * c[2], cq = z[0] * c[0] + z[1] * c[1] + z[2] * c[2];
+      const double r2 = objs[j].r2, r = sqrt(r2);
+      rt_geom q = {-INFINITY, INFINITY, -INFINITY, INFINITY};
+      if (cq + r * (1.0 + 1e-9) + 1e-9 < 0.0) { skip[j] = 1; rect[j] = q; continue; }   // wholly behind the light: cannot lie between it and a point in front
+      const double kk = (cx * cx + cy * cy + cq * cq) - r2;
+      if (kk > 1e-9 * r2 && r2 > 0.0) {
+        axis_bounds(cx, cq, 1.0, 1.0, r2, &q.ox, &q.oy);
+        axis_bounds(cy, cq, 1.0, 1.0, r2, &q.oz, &q.r2);
+      }
+      rect[j] = q;
+      if (std::isfinite(q.ox)) gx0 = fmin(gx0, q.ox);
+      if (std::isfinite(q.oy)) gx1 = fmax(gx1, q.oy);
+      if (std::isfinite(q.oz)) gy0 = fmin(gy0, q.oz);
+      if (std::isfinite(q.r2)) gy1 = fmax(gy1, q.r2);
+    }
+    if (!(gx0 < gx1)) { gx0 = -1.0; gx1 = 1.0; }
+    if (!(gy0 < gy1)) { gy0 = -1.0; gy1 = 1.0; }
+    gx0 = fmax(gx0, -8.0); gx1 = fmin(gx1, 8.0); gy0 = fmax(gy0, -8.0); gy1 = fmin(gy1, 8.0);
+    if (!(gx0 < gx1)) { gx0 = -8.0; gx1 = 8.0; }
+    if (!(gy0 < gy1)) { gy0 = -8.0; gy1 = 8.0; }
+    const double inv_cw = G / (gx1 - gx0), inv_ch = G / (gy1 - gy0);
+    double *hk = hdr + 16u * k;
+    for (int c = 0; c < 3; c++) { hk[c] = x[c]; hk[3 + c] = y[c]; hk[6 + c] = z[c]; }
+    hk[9] = gx0; hk[10] = gy0; hk[11] = inv_cw; hk[12] = inv_ch;
+    auto cell_of = [&](double v, double g0, double inv) -> uint32_t {     // the kernel's own mapping
+      const double f = fmin(fmax((v - g0) * inv, 0.0), (double)(G - 1));
+      return (uint32_t)f;
+    };
+    uint64_t *mk = masks + (size_t)k * cells * words;
+    for (uint32_t j = 0; j < n_loop; j++) {
+      mk[(size_t)(G * G) * words + (j >> 6)] |= 1ull << (j & 63u);                    // the "every sphere" cell
+      if (skip[j]) continue;
+      const uint32_t ix0 = cell_of(rect[j].ox, gx0, inv_cw), ix1 = cell_of(rect[j].oy, gx0, inv_cw);
+      const uint32_t iy0 = cell_of(rect[j].oz, gy0, inv_ch), iy1 = cell_of(rect[j].r2, gy0, inv_ch);
+      for (uint32_t iy = iy0; iy <= iy1; iy++) for (uint32_t ix = ix0; ix <= ix1; ix++) mk[((size_t)iy * G + ix) * words + (j >> 6)] |= 1ull << (j & 63u);
+    }
+  }
+  return buf;
+}
+}  // namespace
+
 // Host-logic probe for tests: the cull rectangle of every sphere, scene order, 4 doubles each.
 extern "C" int rt_scene_cull_rects(const void *blob, size_t bytes, double *out) {
   int rc = rt_scene_validate(blob, bytes);
@@ -210,7 +282,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if ((rc = ensure_device(device))) return rc;
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
-  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr;
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr; s->d_shadow_grid = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -284,6 +356,15 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_lds_image, img.size());
     if (e == hipSuccess) e = hipMemcpy(s->d_lds_image, img.data(), img.size(), hipMemcpyHostToDevice);
   }
+  {
+    // shadow grids, in the loop order the product kernel uses (B when there is an enclosing sphere)
+    const uint32_t n_loop = has_b ? NO - 1 : NO;
+    if (n_loop > RT_SGRID_MIN_LOOP && hd->n_lights > 0) {
+      const std::vector<uint64_t> sg = build_shadow_grid(has_b ? objs_b.data() : pob_a, n_loop, hd->n_lights, s->lights);
+      if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
+      if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    }
+  }
   if (e == hipSuccess && has_b) e = hipMalloc((void **)&s->d_objects_b, objs_b.size() * sizeof(rt_sphere));
   if (e == hipSuccess && has_b) e = hipMemcpy(s->d_objects_b, objs_b.data(), objs_b.size() * sizeof(rt_sphere), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->d_blob, patched.data(), bytes, hipMemcpyHostToDevice);
@@ -294,6 +375,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     if (s->d_geom) (void)hipFree(s->d_geom);
     if (s->d_objects_b) (void)hipFree(s->d_objects_b);
     if (s->d_lds_image) (void)hipFree(s->d_lds_image);
+    if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
     delete s;
     return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
   }
@@ -309,6 +391,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   (void)hipFree(s->d_geom);
   if (s->d_objects_b) (void)hipFree(s->d_objects_b);
   if (s->d_lds_image) (void)hipFree(s->d_lds_image);
+  if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
   delete s;
 }
 
@@ -347,6 +430,8 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.geom_cam = gt + hd.n_objects;
   L.cull = gt + 2 * (size_t)hd.n_objects;
   L.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
+  // the grids are built for the product kernel's order: B if the scene has an enclosing sphere, else the scene's own
+  L.shadow_grid = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && getenv("RT_NO_SHADOW_GRID") == nullptr) ? s->d_shadow_grid : nullptr;
   L.geom_light = gt + 3 * (size_t)hd.n_objects;
   L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
   L.enclosing = order_b ? hd.n_objects - 1 : ~0u;

@@ -9,9 +9,16 @@
 // Workgroup geometry: 256 work-items = 4 waves of 64.  A wave owns an 8x8 pixel block (compact,
 // so its 64 rays stay coherent); the 4 waves sit side by side, so a workgroup owns a 32x8 tile
 // whose every row is one whole 128-byte line of the RGBA8 framebuffer.
+#ifndef RT_WG_THREADS
 #define RT_WG_THREADS 256
-#define RT_TILE_W 32
+#endif
+#define RT_TILE_W (RT_WG_THREADS / 8)   /* waves side by side, 8 pixels each */
 #define RT_TILE_H 8
+
+// Shadow grid (product kernel, scenes with more than RT_SGRID_MIN_LOOP spheres in the loops): cells per axis of a
+// light's projective view of the scene; see build_shadow_grid in rt_api.hip for the buffer layout.
+#define RT_SGRID 32u
+#define RT_SGRID_MIN_LOOP 12u
 
 // Sphere geometry as the uniform object loops read it: 32 bytes, scalar-loaded (s_load_dwordx8).
 struct rt_geom { double ox, oy, oz, r2; };
@@ -25,6 +32,7 @@ struct rt_launch {
   const rt_geom *geom_cam;           // anchored at the camera: {o - cam, |o - cam|^2 - r2} per sphere
   const void *lds_image;             // [materials (n_objects x 192 B) | 16 texture descriptors | cull rectangles]: the workgroup's LDS image
   const rt_geom *cull;               // per sphere {x_lo, x_hi, y_lo, y_hi}: bounds of X/D, Y/D of the pixels whose line meets it
+  const void *shadow_grid;           // per-light shadow grids (rt_api.hip: build_shadow_grid), or NULL when the scene is small
   const rt_geom *geom_light;         // anchored at light k: [k*n_objects + j] = {o_j - light_k, |o_j - light_k|^2 - r2_j}
   const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`
   const uint8_t *texel_base;

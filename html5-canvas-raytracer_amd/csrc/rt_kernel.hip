@@ -202,7 +202,7 @@ template <bool REFRACT> struct frame;
 template <> struct frame<false> { double amb[3], ds[3], a3; };
 template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3]; int has_f, phase; };
 
-template <bool REFRACT, bool COUNT>
+template <bool REFRACT, bool COUNT, bool GRID>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
@@ -448,6 +448,45 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #else
             const uint32_t NS = NLOOP;
 #endif
+#if !RT_STRICT
+            if (GRID && li != 0.0) {
+              // Many spheres: cull the scan with the light's grid.  The host cut light k's view of the scene
+              // (projective coordinates x'/z', y'/z' in a frame looking from the light at the scene) into
+              // RT_SGRID x RT_SGRID cells and stored, per cell, the bit set of spheres whose conservative rectangle
+              // (same construction as the primary-ray cull, with the light as the eye) touches it.  A lane's shadow
+              // ray lies on the line from the light through its hit point, so only the spheres of that point's cell
+              // can block it.  The wave tests the UNION over its active lanes: the distinct cells are walked with
+              // readlane/ballot (correct under divergence: it never relies on inactive lanes), typically 1-4 of them.
+              const double __attribute__((address_space(4))) *gh = (const double __attribute__((address_space(4))) *)L.shadow_grid + 16u * k;
+              const v3 vv = mk(-sraw.x, -sraw.y, -sraw.z);                                   // light -> hit point
+              const double vx = gh[0] * vv.x + gh[1] * vv.y + gh[2] * vv.z, vy = gh[3] * vv.x + gh[4] * vv.y + gh[5] * vv.z;
+              const double vz = gh[6] * vv.x + gh[7] * vv.y + gh[8] * vv.z;
+              const double iz = rt_rcp(vz);
+              const double fx = __builtin_fmin(__builtin_fmax((vx * iz - gh[9]) * gh[11], 0.0), (double)(RT_SGRID - 1));
+              const double fy = __builtin_fmin(__builtin_fmax((vy * iz - gh[10]) * gh[12], 0.0), (double)(RT_SGRID - 1));
+              const bool proj = (vz > 0.0) && (fx == fx) && (fy == fy);
+              const uint32_t cell = proj ? (uint32_t)fy * RT_SGRID + (uint32_t)fx : (uint32_t)(RT_SGRID * RT_SGRID);   // last cell: every sphere
+              const uint32_t words = (NLOOP + 63u) >> 6;
+              const unsigned long long __attribute__((address_space(4))) *cells =
+                  (const unsigned long long __attribute__((address_space(4))) *)((const double __attribute__((address_space(4))) *)L.shadow_grid + 16u * NL) +
+                  (size_t)k * (RT_SGRID * RT_SGRID + 1u) * words;
+              for (uint32_t wd = 0; wd < words && !blocked; wd++) {
+                unsigned long long cand = 0ull, todo = __ballot(true);
+                while (todo) {
+                  const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)__builtin_ctzll(todo));
+                  cand |= cells[(size_t)c0 * words + wd];
+                  todo &= ~__ballot(cell == c0);
+                }
+                while (cand) {
+                  const uint32_t j = (wd << 6) + (uint32_t)__builtin_ctzll(cand);
+                  cand &= cand - 1ull;
+                  const rt_geom g0 = RT_LOAD(gl, j);
+                  RT_SHADOW(j, g0)
+                  if (blocked) break;
+                }
+              }
+            } else
+#endif
             if (COUNT || li != 0.0) {                  // li == 0 on entry (an earlier light was blocked) cannot change
               uint32_t j = 0;
               for (; j + 2 <= NS; j += 2) {
@@ -592,8 +631,36 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
 }
 
-template <bool REFRACT, bool COUNT, bool SS2>
-__global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const rt_launch L) {
+// Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
+// again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
+// the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
+struct rt_pixel { uint32_t px, trow, frow, lrow, sub; bool valid; };
+template <bool SS2>
+__device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
+  // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
+  // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
+  const uint32_t tile_x = blockIdx.x;
+  uint32_t tile_i, row_block;
+  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
+  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
+  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
+  rt_pixel P;
+  P.sub = 0u;                                          // trow = row inside tile `tile_i`
+  if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = row_block * RT_TILE_H + (lane >> 3); }
+  else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = row_block * 2u + (q >> 3); }
+  P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
+  P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
+  P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
+  return P;
+}
+
+template <bool REFRACT, bool COUNT, bool SS2, bool GRID>
+// Register budget: the reflection-only kernel fits 96 VGPRs = 5 waves per SIMD on its own (measured: 4 waves cost 11 %,
+// more than 5 gain nothing); its shadow-grid variant is held there; the general kernel is left free (forcing it to 5
+// waves spills into its loops: -9 %).
+__global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_PER_EU : (RT_WAVES_PER_EU > 5 ? RT_WAVES_PER_EU : 5))) rt_trace(const rt_launch L) {
   extern __shared__ double lds_raw[];
   // ---- stage the per-workgroup tables into LDS: ONE contiguous image in HBM (materials | texture descriptors |
   //      cull rectangles, laid out exactly as the LDS copy), so a workgroup pays one memory latency, not three;
@@ -611,21 +678,9 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
   double *acc = lds_raw + mtl_words + tex_words + cull_words + tid;   // 10 x RT_WG_THREADS doubles, lane-major (product chain kernel only)
 
   // ---- which pixel / sample this work-item owns ----
-  const uint32_t wave = tid >> 6, lane = tid & 63u;
-  // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
-  // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
-  // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
-  const uint32_t tile_x = blockIdx.x, frame_i = blockIdx.z;
-  uint32_t tile_i, row_block;
-  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
-  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
-  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
-  uint32_t px, trow, sub = 0;                          // trow = row inside tile `tile_i`
-  if (!SS2) { px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); trow = row_block * RT_TILE_H + (lane >> 3); }
-  else { const uint32_t q = lane >> 2; sub = lane & 3u; px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); trow = row_block * 2u + (q >> 3); }
-  const uint32_t frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + trow;   // frame row
-  const uint32_t lrow = tile_i * L.tile_rows + trow;                                    // row in this call's output band
-  const bool valid = (px < L.w) && (trow < L.tile_rows) && (frow < L.h);
+  const uint32_t lane = tid & 63u;
+  const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
+  const uint32_t px = P0.px, frow = P0.frow, sub = P0.sub;
   const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px;
   const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
 
@@ -655,19 +710,24 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
   const double lx = SS2 ? (double)(2u * ((lane >> 2) & 7u) + (sub & 1u)) : (double)(lane & 7u);
   const double ly = SS2 ? (double)(2u * (lane >> 5) + (sub >> 1)) : (double)(lane >> 3);
   const double blk_x0 = d0 - lx, blk_x1 = blk_x0 + bw, blk_y1 = d1 + ly, blk_y0 = blk_y1 - bh;
-  trace_pixel<REFRACT, COUNT>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
+  trace_pixel<REFRACT, COUNT, GRID>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
 
   // ---- A10 RGBA8 store ----
+  uint32_t tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));                       // opaque: recompute the pixel instead of keeping it live (see rt_pixel_of)
+  const rt_pixel P1 = rt_pixel_of<SS2>(L, tid2);
+  const uint32_t frame_i = blockIdx.z;
+  const bool valid = P1.valid;
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
   if (!SS2) {
-    if (valid) L.out[(size_t)frame_i * L.frame_stride + (size_t)lrow * L.w + px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+    if (valid) L.out[(size_t)frame_i * L.frame_stride + (size_t)P1.lrow * L.w + P1.px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
   } else {
     // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields)
     uint32_t packed = r8 | (g8 << 10) | (b8 << 20);
     packed += __shfl_xor(packed, 1);
     packed += __shfl_xor(packed, 2);
     const uint32_t R = ((packed & 1023u) + 2u) >> 2, G = (((packed >> 10) & 1023u) + 2u) >> 2, B = (((packed >> 20) & 1023u) + 2u) >> 2;
-    if (valid && sub == 0u) L.out[(size_t)frame_i * L.frame_stride + (size_t)lrow * L.w + px] = R | (G << 8) | (B << 16) | 0xff000000u;
+    if (valid && P1.sub == 0u) L.out[(size_t)frame_i * L.frame_stride + (size_t)P1.lrow * L.w + P1.px] = R | (G << 8) | (B << 16) | 0xff000000u;
   }
 
   if (COUNT) {
@@ -675,7 +735,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, RT_WAVES_PER_EU) rt_trace(const
     for (int c = 0; c < 3; c++) {
       unsigned long long v = valid ? cnt[c] : 0u;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) atomicAdd(&L.counters[c], v);
+      if ((tid2 & 63u) == 0) atomicAdd(&L.counters[c], v);
     }
   }
 }
@@ -687,13 +747,20 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
   // x: 32-pixel tiles across the frame; y: tiles x row blocks (8 rows, or 2 when supersampling); z: frames
   (void)ss2;
   const dim3 grid(L->tiles_x, L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
-#define RT_CASE(R, C, S) hipLaunchKernelGGL((rt_trace<R, C, S>), grid, block, lds_bytes, stream, *L)
-  if (!count) {
-    if (!refract) { if (!ss2) RT_CASE(false, false, false); else RT_CASE(false, false, true); }
-    else          { if (!ss2) RT_CASE(true, false, false);  else RT_CASE(true, false, true); }
+#define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
+  // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
+  const bool grid_variant = !RT_STRICT && !count && L->shadow_grid != nullptr;
+  if (grid_variant) {
+#if !RT_STRICT
+    if (!refract) { if (!ss2) RT_CASE(false, false, false, true); else RT_CASE(false, false, true, true); }
+    else          { if (!ss2) RT_CASE(true, false, false, true);  else RT_CASE(true, false, true, true); }
+#endif
+  } else if (!count) {
+    if (!refract) { if (!ss2) RT_CASE(false, false, false, false); else RT_CASE(false, false, true, false); }
+    else          { if (!ss2) RT_CASE(true, false, false, false);  else RT_CASE(true, false, true, false); }
   } else {
-    if (!refract) { if (!ss2) RT_CASE(false, true, false); else RT_CASE(false, true, true); }
-    else          { if (!ss2) RT_CASE(true, true, false);  else RT_CASE(true, true, true); }
+    if (!refract) { if (!ss2) RT_CASE(false, true, false, false); else RT_CASE(false, true, true, false); }
+    else          { if (!ss2) RT_CASE(true, true, false, false);  else RT_CASE(true, true, true, false); }
   }
 #undef RT_CASE
   return (int)hipGetLastError();

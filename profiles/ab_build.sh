@@ -10,7 +10,7 @@ T=$(mktemp -d)
 COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -I$SRC"
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=0 -ffp-contract=fast -c $SRC/rt_kernel.hip -o $T/kf.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=1 -ffp-contract=off -c $SRC/rt_kernel.hip -o $T/ks.o &
-/opt/rocm/bin/hipcc $COMMON -c $SRC/rt_api.hip -o $T/api.o &
+/opt/rocm/bin/hipcc $COMMON $FLAGS -c $SRC/rt_api.hip -o $T/api.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/librt_hip_$NAME.so $T/api.o $T/kf.o $T/ks.o -ldl
 rm -rf $T

@@ -311,3 +311,22 @@ def test_deinterleave_kernel_wide_and_ragged(lib):
             lib.rt_free_device(0, d_src)
             lib.rt_free_device(0, d_dst)
         assert np.array_equal(np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4), want), (w, h, tile_rows, G)
+
+
+@pytest.mark.parametrize("seed,n,lights", [
+    (21, 16, [[0.0, 2.0, 0.0]]),                                           # light in the middle of the cluster: spheres all around it
+    (22, 40, [[5.0, 10.0, 5.0], [-3.0, 0.6, 2.0]]),                        # a light near the floor, among the spheres
+    (23, 64, [[0.0, 30.0, 0.0], [20.0, 3.0, -10.0], [-1.0, 1.5, 8.0]]),    # straight above / grazing / behind the camera
+    (24, 130, [[5.0, 10.0, 5.0], [5.0, 10.0, 0.0]]),                       # more than 64 spheres: multi-word cell masks
+    (25, 14, [[0.5, 0.4, 0.3]])])                                          # just over the grid threshold, light inside the pile
+def test_shadow_grid_is_exact(lib, seed, n, lights):
+    """Scenes with more than 12 spheres take the product kernel's shadow-grid variant (per-light projective grid of
+    candidate occluders, union over the wave's distinct cells).  The grid only prunes: images must still match the
+    C restatement, which scans every sphere."""
+    s = random_scene(seed, n, False, 3)
+    s["lights"] = lights
+    blob = rt_host.flatten_scene(s)
+    w, h = 192, 128
+    got = gpu_frame(lib, blob, w, h)
+    assert ou.max_lsb(got, ou.c_oracle_render(blob, w, h))[0] <= 1
+    assert ou.max_lsb(got, gpu_frame(lib, blob, w, h, STRICT))[0] <= 1     # the strict kernel has no grid
