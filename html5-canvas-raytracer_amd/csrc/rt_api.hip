@@ -45,6 +45,7 @@ int fail(int code, const char *fmt, ...) {
 struct device_state {
   int hip_id = -1;
   hipStream_t stream = nullptr;          // created on first use
+  hipStream_t copy_stream = nullptr;     // rt_render: PCIe copy-out overlapped with rendering
   unsigned long long *d_counters = nullptr;
   void *d_frame = nullptr;               // rt_render scratch: this device's tiles (or the whole frame)
   size_t frame_bytes = 0;
@@ -647,22 +648,62 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
   memset(&agg, 0, sizeof agg);
 
   if (ndev == 1 || h < (uint32_t)ndev * RT_TILE_H) {
-    // ---- one GPU: one launch, one copy-out ----
+    // ---- one GPU.  Large frames are rendered as a few row bands so that the PCIe copy-out of band i (copy
+    //      stream) runs while band i+1 renders (render stream): the frame costs ~max(render, copy), not the sum ----
     rt_scene_dev *s = nullptr;
     if ((rc = rt_scene_upload(0, blob, bytes, &s))) return rc;
     device_state &D = G.dev[0];
-    rt_tiles whole = {h, 0, 1, 1};
-    rt_stats st;
     rc = ensure_frame(D, frame_bytes);
-    if (!rc) rc = rt_render_tiles_device(s, w, h, &whole, D.d_frame, nullptr, flags, &st);
+    if (!rc && !D.copy_stream) {
+      hipError_t e = hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy stream: %s", hipGetErrorString(e));
+    }
+    const bool count = (flags & RT_FLAG_COUNT) != 0;
+    const uint32_t n_bands = (count || frame_bytes < (8u << 20)) ? 1u : 4u;      // counters come from one instrumented launch
+    const uint32_t band_rows = ((h + n_bands - 1) / n_bands + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, band_done[4] = {nullptr, nullptr, nullptr, nullptr};
     if (!rc) {
-      hipError_t e = hipMemcpyAsync(out_rgba, D.d_frame, frame_bytes, hipMemcpyDeviceToHost, D.stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
-      if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+      rt_stats st;
+      memset(&st, 0, sizeof st);
+      if (n_bands == 1) {
+        rt_tiles whole = {h, 0, 1, 1};
+        rc = rt_render_tiles_device(s, w, h, &whole, D.d_frame, nullptr, flags, &st);
+        if (!rc) {
+          hipError_t e = hipMemcpyAsync(out_rgba, D.d_frame, frame_bytes, hipMemcpyDeviceToHost, D.stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+          if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+        }
+      } else {
+        hipError_t e = hipEventCreate(&ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ev1);
+        if (e == hipSuccess) e = hipEventRecord(ev0, D.stream);
+        for (uint32_t b = 0; b < n_bands && !rc && e == hipSuccess; b++) {
+          const uint32_t r0 = b * band_rows;
+          if (r0 >= h) break;
+          const uint32_t rows = (r0 + band_rows <= h) ? band_rows : h - r0;
+          rt_tiles band = {band_rows, b, 1, 1};
+          uint8_t *d_band = (uint8_t *)D.d_frame + (size_t)r0 * w * 4u;
+          rc = rt_render_tiles_device(s, w, h, &band, d_band, nullptr, flags, nullptr);
+          if (rc) break;
+          e = hipEventCreateWithFlags(&band_done[b], hipEventDisableTiming);
+          if (e == hipSuccess) e = hipEventRecord(band_done[b], D.stream);
+          if (e == hipSuccess) e = hipStreamWaitEvent(D.copy_stream, band_done[b], 0);
+          if (e == hipSuccess) e = hipMemcpyAsync(out_rgba + (size_t)r0 * w * 4u, d_band, (size_t)rows * w * 4u, hipMemcpyDeviceToHost, D.copy_stream);
+        }
+        if (e == hipSuccess && !rc) e = hipEventRecord(ev1, D.stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.copy_stream);
+        if (e == hipSuccess && !rc) { float ms = 0.f; e = hipEventElapsedTime(&ms, ev0, ev1); st.kernel_ms = ms; }
+        if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "banded render/copy-out: %s", hipGetErrorString(e));
+        st.pixels = (uint64_t)w * h;
+        for (hipEvent_t ev : band_done) if (ev) (void)hipEventDestroy(ev);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+      }
+      agg = st;
     }
     rt_scene_free(s);
     if (rc) return rc;
-    agg = st;
   } else {
     // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
     //      GPU stores its tiles contiguously, ONE RCCL gather to GPU 0 over xGMI, one de-interleave pass ----
@@ -752,6 +793,7 @@ extern "C" void rt_shutdown(void) {
     if (D.d_gather) (void)hipFree(D.d_gather);
     if (D.d_counters) (void)hipFree(D.d_counters);
     (void)hipStreamDestroy(D.stream);
+    if (D.copy_stream) (void)hipStreamDestroy(D.copy_stream);
     D = device_state();
   }
   G.dev.clear();

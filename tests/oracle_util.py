@@ -83,5 +83,5 @@ def max_lsb(a, b):
     a = np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a
     b = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else b
     assert a.size == b.size, (a.size, b.size)
-    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    d = np.abs(a.reshape(-1).astype(np.int16) - b.reshape(-1).astype(np.int16))
     return int(d.max()), float((d > 0).mean())

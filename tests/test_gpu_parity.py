@@ -330,3 +330,21 @@ def test_shadow_grid_is_exact(lib, seed, n, lights):
     got = gpu_frame(lib, blob, w, h)
     assert ou.max_lsb(got, ou.c_oracle_render(blob, w, h))[0] <= 1
     assert ou.max_lsb(got, gpu_frame(lib, blob, w, h, STRICT))[0] <= 1     # the strict kernel has no grid
+
+
+def test_render_entry_point_large_frame_banded_copy_out(lib):
+    """rt_render at 3840x2160: the frame is rendered as row bands whose PCIe copy-out overlaps the next band's
+    render; the assembled host frame must equal the device-resident single-launch frame byte for byte."""
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    w, h = 3840, 2160
+    rgba, st = rt_host.render(w, h, blob, lib=lib)
+    assert st.pixels == w * h and st.kernel_ms > 0
+    assert rgba == gpu_frame(lib, blob, w, h)
+    f = FRAMES["h8_3840x2160_rows"]
+    got = np.frombuffer(rgba, dtype=np.uint8).reshape(h, w * 4)[f["rows"]]
+    assert ou.max_lsb(np.ascontiguousarray(got), ou.golden_frame(f))[0] <= 1
+    # a height that is not a multiple of the band size, and the counting path (single launch)
+    rgba2, st2 = rt_host.render(2048, 1031, blob, lib=lib)
+    assert rgba2 == gpu_frame(lib, blob, 2048, 1031)
+    _, st3 = rt_host.render(2048, 1031, blob, flags=rt_host.RT_FLAG_COUNT, lib=lib)
+    assert st3.rays > 2048 * 1031
