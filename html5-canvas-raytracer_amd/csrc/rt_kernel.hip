@@ -5,7 +5,7 @@
 //   A2  ray-sphere intersection         :420-451
 //   A3  closest hit, strict <           :223-231
 //   A4  reflection / A5 refraction      :233-266
-//   A6  bounded recursion               :221, :268-278       (explicit per-lane stack, post-order fold)
+//   A6  bounded recursion               :221, :268-278       (stackless forward fold, or explicit per-lane stack)
 //   A7  lights, shadows, Phong          :280-318              (light_intensity shared across lights, q2)
 //   A8  samplers (colour/texture/checker) :404, :343-351, :126-133
 //   A9  combine + non-linear clamp      :320-336
@@ -16,21 +16,26 @@
 //   * one work-item per pixel (per SAMPLE when supersampling); a wave owns a compact 8x8 block so its
 //     64 rays take the same branches; 4 waves side by side make a 32x8 workgroup tile = whole
 //     128-byte framebuffer lines, each line written by exactly one workgroup (no cross-XCD sharing);
-//   * everything wave-uniform — camera, lights, loop bounds (kernarg) and the sphere geometry walked
-//     by the uniform object loops — is read with SCALAR loads into SGPRs, so the intersection loops
-//     issue no vector memory and no LDS traffic at all;
+//     grid = (tiles across, tiles x row blocks, frames of the batch): no integer division in the kernel;
+//   * everything wave-uniform — camera, lights, loop bounds (kernarg) and the sphere tables walked by
+//     the uniform object loops (typed address_space(4)) — is read with SCALAR loads into SGPRs: the
+//     intersection loops issue no vector memory and no LDS instruction;
 //   * the per-hit, per-lane data (material + sampler parameters of the sphere that lane hit, texture
-//     descriptors) is staged once per workgroup into LDS and indexed by the lane's hit id;
-//   * texels are plain global loads (gfx950 has no image/texture path); the two 128 KB textures
-//     stay L2-resident;
-//   * divergent phases are guarded by exec-mask branches the compiler lowers to s_cbranch_execz
-//     (whole-wave skip of the sqrt path when no lane's ray meets the sphere, of lighting when every
-//     lane hit an emissive-only surface, of the shadow scan when every lane is already occluded),
-//     and the bounce loop runs while __ballot says any lane still has a ray in flight.
+//     descriptors), the primary-ray cull rectangles and the 10-double state of the stackless recursion
+//     fold live in LDS; the LDS image is one contiguous block in HBM, loaded behind the ray generation;
+//   * texels are plain global loads (gfx950 has no image/texture path); the two 128 KB textures stay
+//     L2-resident;
+//   * product kernel only: "anchored" line-sphere discriminants for primary rays (camera) and shadow
+//     rays (walked from the light): 4 operations instead of 10; a wave-wide cull of primary-ray
+//     candidates (__ballot over per-sphere screen rectangles); per-light shadow grids when the scene has
+//     many spheres; an enclosing sphere (skybox) kept out of the loops; hardware rsq/rcp + Newton;
+//   * divergent phases are exec-mask branches the compiler lowers to s_cbranch_execz; the bookkeeping of
+//     a hit is pinned inside its branch, so a wave whose 64 rays all miss a sphere pays 4 FP64 operations
+//     and one compare for it.
 //
-// The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (default product
-// kernel) and RT_STRICT=1 with -ffp-contract=off (operation-for-operation with the JS expression
-// trees; RT_FLAG_STRICT_FP).
+// The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (the product kernel)
+// and RT_STRICT=1 with -ffp-contract=off (operation for operation with the JS expression trees, IEEE
+// sqrt/div, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB.
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -404,8 +409,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             const double sdot = dot(sv, l);
             if (sdot <= 0.0) continue;                                 // surface faces away
             if (COUNT) cnt[1]++;
-            // Shadow scan (main.js:293-304).  `alive` is the per-lane "not yet fully blocked" flag; the
-            // loop leaves early only when every lane of the wave is blocked (exec-mask loop exit).
             // Shadow scan (main.js:293-304) over every sphere but the one just hit (q3).  A fully blocked lane
             // keeps li == 0 whatever follows, so leaving the loop is a pure shortcut, taken per pair.
             uint32_t tests = 0;
