@@ -188,3 +188,29 @@ def test_cull_rectangles_are_conservative(built):
             cols = np.where(line_meets.any(0))[0]
             assert (X[0, cols[0]] / D - x0) * D < 1.5 and (x1 - X[0, cols[-1]] / D) * D < 1.5
     assert bounded > 20
+
+
+def test_validator_survives_corrupted_blobs(built):
+    """Truncated and randomly corrupted blobs are rejected (or accepted) without crashing; whatever the validator
+    accepts, the host-side scene analysis (cull rectangles) must digest.  The same loop was run once against an
+    AddressSanitizer build of the library (hipcc -fsanitize=address -fno-gpu-sanitize): clean."""
+    import random
+    lib = rt_host.load_library()
+    rng = random.Random(5)
+    for name in ("cfg2", "default14", "lcg64"):
+        blob = rt_host.flatten_scene(rt_host.load_scene(name))
+        n = struct.unpack_from("<I", blob, 168)[0]
+        out = (C.c_double * (4 * n))()
+        for cut in (0, 8, 100, 207, 208, 300, len(blob) - 1):
+            b = C.create_string_buffer(blob[:cut], max(cut, 1))
+            assert lib.rt_scene_validate(b, cut) != 0
+        accepted = 0
+        for _ in range(200):
+            b = bytearray(blob)
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(0, 208 + 192 * n + 64)] = rng.randrange(256)
+            buf = C.create_string_buffer(bytes(b), len(b))
+            if lib.rt_scene_validate(buf, len(b)) == 0:
+                accepted += 1
+                assert lib.rt_scene_cull_rects(buf, len(b), out) == 0
+        assert accepted > 0
