@@ -410,6 +410,7 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "frame size %ux%u not in 1..65536", w, h);
   if (tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0) return fail(RT_ERR_INVALID, "empty tile set");
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows > (1ull << 24)) return fail(RT_ERR_INVALID, "too many rows in one call");
+  if ((uint64_t)tiles->n_tiles * tiles->tile_rows * w >= (1ull << 32)) return fail(RT_ERR_INVALID, "a call may cover at most 2^32 - 1 pixels per frame");
   int rc = ensure_device(s->device);
   if (rc) return rc;
   device_state &D = G.dev[s->device];

@@ -698,7 +698,11 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const v3 ray = unit(mk(target.x - o.x, target.y - o.y, target.z - o.z), &rl);
 #else
   // target[k] - origin[k] = (axisX[k] + axisY[k] + axisZ[k]) * dist[k]; the sums come from the host
-  const v3 ray = unit(mk(L.cam_axis_sum[0] * d0, L.cam_axis_sum[1] * d1, L.cam_axis_sum[2] * d2), &rl);
+  // (its z component is axis_sum.z * projD: never the zero vector unless the camera is degenerate, and then the
+  // reference divides by zero as well, so no zero-length select here)
+  const v3 rawray = mk(L.cam_axis_sum[0] * d0, L.cam_axis_sum[1] * d1, L.cam_axis_sum[2] * d2);
+  rl = rt_rsqrt_pos(dot(rawray, rawray));
+  const v3 ray = mk(rawray.x * rl, rawray.y * rl, rawray.z * rl);
 #endif
 
   double rgb[3];
@@ -723,14 +727,14 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const bool valid = P1.valid;
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
   if (!SS2) {
-    if (valid) L.out[(size_t)frame_i * L.frame_stride + (size_t)P1.lrow * L.w + P1.px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+    if (valid) (L.out + (size_t)frame_i * L.frame_stride)[P1.lrow * L.w + P1.px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;   // a band holds < 2^32 pixels (host check)
   } else {
     // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields)
     uint32_t packed = r8 | (g8 << 10) | (b8 << 20);
     packed += __shfl_xor(packed, 1);
     packed += __shfl_xor(packed, 2);
     const uint32_t R = ((packed & 1023u) + 2u) >> 2, G = (((packed >> 10) & 1023u) + 2u) >> 2, B = (((packed >> 20) & 1023u) + 2u) >> 2;
-    if (valid && P1.sub == 0u) L.out[(size_t)frame_i * L.frame_stride + (size_t)P1.lrow * L.w + P1.px] = R | (G << 8) | (B << 16) | 0xff000000u;
+    if (valid && P1.sub == 0u) (L.out + (size_t)frame_i * L.frame_stride)[P1.lrow * L.w + P1.px] = R | (G << 8) | (B << 16) | 0xff000000u;
   }
 
   if (COUNT) {
