@@ -348,3 +348,33 @@ def test_render_entry_point_large_frame_banded_copy_out(lib):
     assert rgba2 == gpu_frame(lib, blob, 2048, 1031)
     _, st3 = rt_host.render(2048, 1031, blob, flags=rt_host.RT_FLAG_COUNT, lib=lib)
     assert st3.rays > 2048 * 1031
+
+
+def _look_at(org, tgt, up):
+    """main.js:92-100 in numpy (host-side helper of the test only)."""
+    org, tgt, up = (np.array(v, dtype=np.float64) for v in (org, tgt, up))
+    z = tgt - org
+    x = np.cross(up, z)
+    y = np.cross(z, x)
+    unit = lambda v: v * (1.0 / np.sqrt((v * v).sum())) if (v * v).sum() != 0 else v
+    return {"origin": org.tolist(), "axisX": unit(x).tolist(), "axisY": unit(y).tolist(), "axisZ": unit(z).tolist()}
+
+
+@pytest.mark.parametrize("org,tgt,up,fov", [
+    ([6.0, 3.0, 8.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0], 60.0),        # oblique: every axis has x, y and z parts (quirk q1 in full)
+    ([0.0, 9.0, 0.5], [0.0, 0.0, 0.0], [0.0, 0.0, -1.0], 75.0),       # looking down
+    ([-3.0, 0.4, -6.0], [1.0, 1.0, 0.0], [0.0, 1.0, 0.0], 35.0),      # low, from behind, narrow
+    ([0.0, 1.5, 10.0], [0.0, 1.5, 0.0], [0.0, 1.0, 0.0], 150.0),      # the reference camera, very wide
+    ([0.0, 1.0, 0.2], [0.0, 1.0, -2.0], [0.0, 1.0, 0.0], 60.0)])      # inside the scene, next to a sphere
+def test_general_cameras(lib, org, tgt, up, fov):
+    """The reference builds target[k] from dist[k] per COMPONENT (main.js:187-191), which is a pinhole only for its
+    own axis-aligned camera.  Whatever the camera, kernel and oracle must agree: this exercises the anchored
+    discriminants, the screen-rectangle cull (including axes whose component sum is 0) and the shadow grids away
+    from the default view."""
+    for name in ("h8", "lcg64_ss1"):
+        s = rt_host.load_scene(name)
+        s["camera"] = _look_at(org, tgt, up)
+        s["fovDeg"] = fov
+        blob = rt_host.flatten_scene(s)
+        w, h = 160, 96
+        assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1, name
