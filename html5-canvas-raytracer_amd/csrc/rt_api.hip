@@ -145,8 +145,8 @@ extern "C" int rt_scene_validate(const void *blob, size_t bytes) {
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   for (uint32_t i = 0; i < hd->n_objects; i++) {
     const int k = ob[i].sampler_kind;
-    if (k != RT_SAMPLER_COLOR && k != RT_SAMPLER_TEXTURE && k != RT_SAMPLER_CHECKER)
-      return fail(RT_ERR_UNSUPPORTED, "object %u: sampler kind %d is not supported (the Math.random stars sampler of main.js:135-139 cannot be reproduced)", i, k);
+    if (k != RT_SAMPLER_COLOR && k != RT_SAMPLER_TEXTURE && k != RT_SAMPLER_CHECKER && k != RT_SAMPLER_STARS)
+      return fail(RT_ERR_UNSUPPORTED, "object %u: sampler kind %d is not supported (0 colour, 1 texture, 2 checker, 3 hashed stars)", i, k);
     if (k == RT_SAMPLER_TEXTURE && (ob[i].texture < 0 || (uint32_t)ob[i].texture >= hd->n_textures))
       return fail(RT_ERR_INVALID, "object %u: texture index %d out of range", i, ob[i].texture);
   }

@@ -163,6 +163,17 @@ __device__ __forceinline__ v3 reflect(const v3 v, const v3 n) {
 __device__ __forceinline__ double min1(double x) { return (x > 1.0) ? 1.0 : x; }
 __device__ __forceinline__ double maxa(double a, double x) { return (x < a) ? a : x; }
 
+// Counter-based stand-in for Math.random() in the stars sampler (main.js:135-139): lowbias32 twice over the sample's
+// index in the frame and the node's position in the ray tree (root 1, reflect child 2p, refract child 2p+1).
+// Identical in oracle/restate.js and oracle/rt_oracle.c.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ double star_uniform(uint32_t pix_lo, uint32_t pix_hi, uint32_t path) {
+  return (double)lowbias32(pix_lo ^ lowbias32(path + 0x9e3779b9u * (pix_hi + 1u))) * (1.0 / 4294967296.0);
+}
+
 // ECMAScript ToInt32(x) & 1   (main.js:129-130)
 __device__ __forceinline__ int to_int32_bit0(double x) {
   if (!(fabs(x) < RT_INF)) return 0;                 // NaN, +-Infinity -> 0
@@ -200,6 +211,31 @@ __device__ __forceinline__ uint32_t to_byte(double c) {
 typedef const rt_geom __attribute__((address_space(4))) *geom_kptr;
 typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 
+// Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
+// again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
+// the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
+struct rt_pixel { uint32_t px, trow, frow, lrow, sub; bool valid; };
+template <bool SS2>
+__device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
+  // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
+  // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
+  const uint32_t tile_x = blockIdx.x;
+  uint32_t tile_i, row_block;
+  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
+  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
+  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
+  rt_pixel P;
+  P.sub = 0u;                                          // trow = row inside tile `tile_i`
+  if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = row_block * RT_TILE_H + (lane >> 3); }
+  else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = row_block * 2u + (q >> 3); }
+  P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
+  P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
+  P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
+  return P;
+}
+
 // A frame of the explicit recursion stack: everything intersectWorld still needs after its
 // recursive calls return (main.js:320-336) — the lighting and sampler terms do not depend on the
 // children, so they are evaluated before descending.
@@ -207,7 +243,7 @@ template <bool REFRACT> struct frame;
 template <> struct frame<false> { double amb[3], ds[3], a3; };
 template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3]; int has_f, phase; };
 
-template <bool REFRACT, bool COUNT, bool GRID>
+template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
@@ -225,6 +261,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #endif
   [[maybe_unused]] frame<REFRACT> stack[FOLD_FORWARD ? 1 : RT_MAX_SEGS];
   int level = 0;
+  [[maybe_unused]] uint32_t tree_path = 1u;            // general kernel: position in the ray tree (root 1, reflect 2p, refract 2p+1)
 #ifdef RT_ABLATE_BOUNCE
   uint32_t segs_left = L.segs ? 1 : 0;
 #else
@@ -365,6 +402,18 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           const double v = RT_DIV_CONST(asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
           col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
+        } else if (kind == RT_SAMPLER_STARS) {
+          // the sample's index in the FRAME (not in this call's tiles), recomputed from the work-item id so that it
+          // costs no register outside this branch; `path` is the node's position in the ray tree
+          uint32_t t3 = threadIdx.x;
+          asm volatile("" : "+v"(t3));
+          const rt_pixel P = rt_pixel_of<SS2>(L, t3);
+          const uint32_t sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px, sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
+          const unsigned long long pix = (unsigned long long)sy * (SS2 ? 2u * L.w : L.w) + sx;
+          const uint32_t path = REFRACT ? tree_path : (1u << level);
+          double c = star_uniform((uint32_t)pix, (uint32_t)(pix >> 32), path);
+          c = (c >= m.checker_freq[0]) ? 0.0 : c * m.checker_freq[1];     // main.js:137-138
+          col[0] = col[1] = col[2] = c;
         } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
 
         // A4 reflection direction
@@ -584,6 +633,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             fr.has_f = go_f; fr.phase = go_r ? 0 : 1;
           }
           p = h; d = go_r ? r : f;
+          tree_path = 2u * tree_path + (go_r ? 0u : 1u);
           level++; segs_left--;
           descend = true;
         }
@@ -603,7 +653,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         // ---------------- return `ret` to the parents (post-order fold, main.js:268-278, :326-336) ----------------
         bool resumed = false;
         while (level > 0) {
-          level--; segs_left++;
+          level--; segs_left++; tree_path >>= 1;
           frame<REFRACT> &fr = stack[level];
           if constexpr (REFRACT) {
             if (fr.phase == 0) {
@@ -611,6 +661,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
               if (fr.has_f) {                            // now the refraction child of the same node
                 fr.phase = 1;
                 p = mk(fr.h[0], fr.h[1], fr.h[2]); d = mk(fr.f[0], fr.f[1], fr.f[2]);
+                tree_path = 2u * tree_path + 1u;
                 level++; segs_left--;
                 resumed = true;
                 break;
@@ -632,31 +683,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   }
 #undef RT_LOAD
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
-}
-
-// Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
-// again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
-// the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
-struct rt_pixel { uint32_t px, trow, frow, lrow, sub; bool valid; };
-template <bool SS2>
-__device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
-  const uint32_t wave = tid >> 6, lane = tid & 63u;
-  // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
-  // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
-  // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
-  const uint32_t tile_x = blockIdx.x;
-  uint32_t tile_i, row_block;
-  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
-  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
-  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
-  rt_pixel P;
-  P.sub = 0u;                                          // trow = row inside tile `tile_i`
-  if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = row_block * RT_TILE_H + (lane >> 3); }
-  else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = row_block * 2u + (q >> 3); }
-  P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
-  P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
-  P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
-  return P;
 }
 
 template <bool REFRACT, bool COUNT, bool SS2, bool GRID>
@@ -717,7 +743,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const double lx = SS2 ? (double)(2u * ((lane >> 2) & 7u) + (sub & 1u)) : (double)(lane & 7u);
   const double ly = SS2 ? (double)(2u * (lane >> 5) + (sub >> 1)) : (double)(lane >> 3);
   const double blk_x0 = d0 - lx, blk_x1 = blk_x0 + bw, blk_y1 = d1 + ly, blk_y0 = blk_y1 - bh;
-  trace_pixel<REFRACT, COUNT, GRID>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
+  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
 
   // ---- A10 RGBA8 store ----
   uint32_t tid2 = threadIdx.x;

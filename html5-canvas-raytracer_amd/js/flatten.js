@@ -43,6 +43,7 @@ function flattenScene(scene) {
     vec(m.color, 3); f64(m.specular_exponent);
     vec(m.albedo, 5); f64(m.refract_index);
     if (s.kind === S.SAMPLER_CHECKER) { f64(s.freqU); f64(s.freqV); vec(s.colors[0], 3); vec(s.colors[1], 3); }
+    else if (s.kind === S.SAMPLER_STARS) { f64(s.threshold); f64(s.scale); for (let i = 0; i < 6; i++) f64(0); }
     else { for (let i = 0; i < 8; i++) f64(0); }
     dv.setInt32(o, s.kind, LE); o += 4;
     dv.setInt32(o, s.kind === S.SAMPLER_TEXTURE ? s.texture : -1, LE); o += 4;

@@ -14,11 +14,12 @@
 //   kind 0 'color'    constant mtl.color                       (:404)
 //   kind 1 'texture'  nearest-texel lookup at hit.u,hit.v       (:143-145, :343-351)
 //   kind 2 'checker'  sphere checker on its own u,v             (:126-133)
-//   ('stars' :135-139 is Math.random-driven; it is rejected, not faked)
+//   kind 3 'stars'    night stars :135-139 with Math.random() replaced by a counter-based hash of (sample index,
+//                     position in the ray tree): deterministic, NOT comparable with the random reference
 
 const {readPNG} = require('./png.js');
 
-const SAMPLER_COLOR = 0, SAMPLER_TEXTURE = 1, SAMPLER_CHECKER = 2;
+const SAMPLER_COLOR = 0, SAMPLER_TEXTURE = 1, SAMPLER_CHECKER = 2, SAMPLER_STARS = 3;
 
 function sub(a, b) { return [a[0] - b[0], a[1] - b[1], a[2] - b[2]]; }
 function cross(a, b) {
@@ -99,6 +100,11 @@ function checkerSampler(freqU, freqV, colors) {
   return {kind: SAMPLER_CHECKER, freqU, freqV, colors: [colors[0].slice(0, 3), colors[1].slice(0, 3)]};
 }
 
+// main.js:135-139 with its literals (0.001, 1000) as parameters and a hash in place of Math.random()
+function starsSampler(threshold, scale) {
+  return {kind: SAMPLER_STARS, threshold: threshold === undefined ? 0.001 : threshold, scale: scale === undefined ? 1000 : scale};
+}
+
 // main.js:159-163 — ascending surface_area / distance-to-camera; Array.prototype.sort is
 // stable in V8 >= 7.0, which is what pins the tie order (SURVEY q4).
 function sortObjects(objects, cameraOrigin) {
@@ -143,14 +149,15 @@ function validateScene(scene) {
     if (!m || !isVec(m.color, 3) || !isVec(m.albedo, 5)) throw new Error('object ' + i + ': material');
     const s = m.sampler;
     if (typeof s === 'function') throw new Error('object ' + i + ': sampler closures cannot cross to the GPU; use colorSampler/textureSampler/checkerSampler');
-    if (!s || ![SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER].includes(s.kind)) throw new Error('object ' + i + ': unsupported sampler kind (the Math.random stars sampler of main.js:135-139 is not supported)');
+    if (!s || ![SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS].includes(s.kind)) throw new Error('object ' + i + ': unsupported sampler kind (use colorSampler/textureSampler/checkerSampler/starsSampler)');
+    if (s.kind === SAMPLER_STARS && !(typeof s.threshold === 'number' && typeof s.scale === 'number')) throw new Error('object ' + i + ': stars sampler parameters');
     if (s.kind === SAMPLER_TEXTURE && !(Number.isInteger(s.texture) && s.texture >= 0 && s.texture < scene.textures.length)) throw new Error('object ' + i + ': texture index out of range');
     if (s.kind === SAMPLER_CHECKER && !(typeof s.freqU === 'number' && typeof s.freqV === 'number' && isVec(s.colors[0], 3) && isVec(s.colors[1], 3))) throw new Error('object ' + i + ': checker sampler parameters');
   });
 }
 
 module.exports = {
-  SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER,
+  SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS, starsSampler,
   lookAt, createMaterial, createSphere, createTexture, checkerTexture, loadTexture, textureFromRGBA,
   colorSampler, textureSampler, checkerSampler, sortObjects, createScene, validateScene,
 };

@@ -47,9 +47,11 @@ function h8(tex, segs) {
 
 // The reference's own 14-sphere scene (main.js:107-157) with the stars sampler
 // pinned to black (Math.random stubbed to 0.5); depth 8 (main.js:194).
-function default14(tex) {
+function default14(tex, stars) {
   const checker = S.checkerTexture(S.createTexture(), 16, 8, [0, 0, 0], [1, 1, 1]);
-  const objs = [home(), skybox(), earth(0), mars(1), matte(2), glass(), chromeA(), chromeB(), bubble(),
+  const sky = skybox();
+  if (stars) sky.mtl.sampler = S.starsSampler(0.001, 1000);   // main.js:135-139, hashed instead of Math.random()
+  const objs = [home(), sky, earth(0), mars(1), matte(2), glass(), chromeA(), chromeB(), bubble(),
     mirror(), metal(), ornament(-1.5, 0, [1, 0, 0]), ornament(1.5, 0, [0, 1, 0]), ornament(0, -2, [0, 0, 1])];
   return finish(objs, [tex.earth, tex.mars, checker], {segs: 8});
 }

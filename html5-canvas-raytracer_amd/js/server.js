@@ -30,7 +30,7 @@ const PAGE = `<!DOCTYPE html>
   const canvas = document.getElementById('canvasID');
   canvas.width = document.body.clientWidth; canvas.height = document.body.clientHeight;
   const ctx = canvas.getContext('2d');
-  const scene = new URLSearchParams(location.search).get('scene') || 'default14';
+  const scene = new URLSearchParams(location.search).get('scene') || 'default14_stars';
   const t0 = Date.now();
   const r = await fetch('/frame?scene=' + scene + '&w=' + canvas.width + '&h=' + canvas.height);
   if (!r.ok) { ctx.fillStyle = '#f44'; ctx.font = '16px monospace'; ctx.fillText((await r.json()).error, 8, 24); return; }
@@ -77,7 +77,7 @@ function createServer(opts) {
       const w = parseInt(u.query.w, 10), h = parseInt(u.query.h, 10);
       if (!(w > 0 && h > 0 && w <= 65536 && h <= 65536 && w * h <= maxPixels)) return sendJSON(res, 400, {error: 'w and h must be positive integers within the frame limit'});
       let scene;
-      try { scene = loadNamedScene(String(u.query.scene || 'default14')); } catch (e) { return sendJSON(res, e.status || 500, {error: e.message}); }
+      try { scene = loadNamedScene(String(u.query.scene || 'default14_stars')); } catch (e) { return sendJSON(res, e.status || 500, {error: e.message}); }
       // renderAsync keeps the event loop free while the GPU works; the reply streams the pinned frame
       return RT.renderAsync(w, h, scene).then((data) => {
         res.writeHead(200, {'Content-Type': 'application/octet-stream', 'Content-Length': data.length, 'X-Width': w, 'X-Height': h,
@@ -93,5 +93,5 @@ module.exports = {createServer, listScenes, PAGE};
 
 if (require.main === module) {
   const port = parseInt(process.argv[2] || '8080', 10);
-  createServer().listen(port, '127.0.0.1', () => console.log('mi355x-sphere-tracer bridge on http://127.0.0.1:' + port + '/?scene=default14'));
+  createServer().listen(port, '127.0.0.1', () => console.log('mi355x-sphere-tracer bridge on http://127.0.0.1:' + port + '/?scene=default14_stars'));
 }

@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(HERE, "csrc", "librt_hip
 RT_SCENE_MAGIC = 0x31535452
 RT_ABI_VERSION = 1
 HEADER_BYTES, SPHERE_BYTES, TEXDESC_BYTES = 208, 192, 16
-SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER = 0, 1, 2
+SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS = 0, 1, 2, 3
 
 RT_FLAG_COUNT = 1
 RT_FLAG_STRICT_FP = 2
@@ -65,9 +65,8 @@ def validate_scene(scene):
         raise ValueError("scene.lights must hold 0..16 lights")
     for i, o in enumerate(scene["objects"]):
         s = o["mtl"]["sampler"]
-        if s["kind"] not in (SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER):
-            raise ValueError("object %d: unsupported sampler kind (the Math.random stars sampler "
-                             "of main.js:135-139 is not supported)" % i)
+        if s["kind"] not in (SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS):
+            raise ValueError("object %d: unsupported sampler kind %r (0 colour, 1 texture, 2 checker, 3 hashed stars)" % (i, s["kind"]))
         if s["kind"] == SAMPLER_TEXTURE and not (0 <= s["texture"] < len(scene["textures"])):
             raise ValueError("object %d: texture index out of range" % i)
 
@@ -102,6 +101,8 @@ def flatten_scene(scene):
         s = m["sampler"]
         if s["kind"] == SAMPLER_CHECKER:
             ck = [s["freqU"], s["freqV"], *s["colors"][0], *s["colors"][1]]
+        elif s["kind"] == SAMPLER_STARS:
+            ck = [s["threshold"], s["scale"], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
         else:
             ck = [0.0] * 8
         rec = struct.pack("<22d2id", *ob["origin"], ob["r2"], *m["color"], m["specular_exponent"],

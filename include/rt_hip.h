@@ -37,7 +37,7 @@ extern "C" {
 typedef enum rt_status {
   RT_OK = 0,
   RT_ERR_INVALID = -1,     /* malformed scene blob / bad argument */
-  RT_ERR_UNSUPPORTED = -2, /* e.g. sampler kind 3 (Math.random stars, main.js:135-139) */
+  RT_ERR_UNSUPPORTED = -2, /* e.g. an unknown sampler kind */
   RT_ERR_DEVICE = -3,      /* HIP / RCCL failure, or no GPU */
   RT_ERR_NOMEM = -4,
   RT_ERR_STATE = -5        /* rt_init not called, bad handle */
@@ -47,7 +47,11 @@ typedef enum rt_status {
 enum {
   RT_SAMPLER_COLOR = 0,   /* main.js:404       constant mtl.color                 */
   RT_SAMPLER_TEXTURE = 1, /* main.js:143-145   sampleTexture(tex, hit.u, hit.v)   */
-  RT_SAMPLER_CHECKER = 2  /* main.js:126-133   sphere checker on its own u,v      */
+  RT_SAMPLER_CHECKER = 2, /* main.js:126-133   sphere checker on its own u,v      */
+  RT_SAMPLER_STARS = 3    /* main.js:135-139   night stars, with Math.random() replaced by a counter-based hash of
+                           *                    (sample index in the frame, position in the ray tree): deterministic, the same
+                           *                    on every implementation here, NOT comparable with the (random) reference.
+                           *                    checker_freq[0] = threshold (0.001), checker_freq[1] = scale (1000). */
 };
 
 /* One sphere + its material: createSphere (main.js:408-418) + createMaterial (:397-406).

@@ -38,6 +38,7 @@ const scenes = {
   h8: SC.h8(tex, 3),
   h8_d8: SC.h8(tex, 8),
   default14: SC.default14(tex),
+  default14_stars: SC.default14(tex, true),     // scene only: the reference's stars are Math.random, nothing to compare with
   lcg64: SC.lcg64(5, 2),
   lcg64_ss1: SC.lcg64(5, 1),
 };

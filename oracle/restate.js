@@ -59,12 +59,18 @@ function renderPlain(w, h, scene, row0, row1, rowList) {
     A0[i] = m.albedo[0]; A1[i] = m.albedo[1]; A2[i] = m.albedo[2]; A3[i] = m.albedo[3]; A4[i] = m.albedo[4];
     KIND[i] = s.kind; TEX[i] = s.kind === 1 ? s.texture : -1;
     if (s.kind === 2) { FU[i] = s.freqU; FV[i] = s.freqV; for (let k = 0; k < 6; k++) CK[i * 6 + k] = s.colors[(k / 3) | 0][k % 3]; }
+    if (s.kind === 3) { FU[i] = s.threshold; FV[i] = s.scale; }
   });
   const LX = new Float64Array(NL), LY = new Float64Array(NL), LZ = new Float64Array(NL);
   scene.lights.forEach((l, k) => { LX[k] = l[0]; LY[k] = l[1]; LZ[k] = l[2]; });
   const TW = scene.textures.map((t) => t.width), TH = scene.textures.map((t) => t.height), TT = scene.textures.map((t) => t.texels);
 
   const res = new Float64Array(3 * (SEGS + 2));   // result slot per recursion level
+  let pixLo = 0, pixHi = 0;                       // sample index in the frame (hashed stars sampler)
+  // Counter-based stand-in for Math.random() in the stars sampler (main.js:135-139); NOT comparable with the
+  // reference (random) — identical in rt_oracle.c and in the HIP kernel.
+  const lowbias32 = (x) => { x ^= x >>> 16; x = Math.imul(x, 0x7feb352d); x ^= x >>> 15; x = Math.imul(x, 0x846ca68b); x ^= x >>> 16; return x >>> 0; };
+  const starUniform = (path) => lowbias32((pixLo ^ lowbias32((path + Math.imul(0x9e3779b9, pixHi + 1)) >>> 0)) >>> 0) / 4294967296;
   let nRays = 0, nShadow = 0, nTests = 0;
   let hitInside = false;                          // side output of isect()
 
@@ -89,7 +95,8 @@ function renderPlain(w, h, scene, row0, row1, rowList) {
   }
 
   // main.js:220-337; writes rgb to res[3*lvl..]
-  function trace(segs, lvl, px, py, pz, dx, dy, dz) {
+  // path: position in the ray tree (root 1, reflect child 2p, refract child 2p+1)
+  function trace(segs, lvl, path, px, py, pz, dx, dy, dz) {
     const o = 3 * lvl;
     if (segs === 0) { res[o] = 0; res[o + 1] = 0; res[o + 2] = 0; return; }
     nRays++;
@@ -139,11 +146,11 @@ function renderPlain(w, h, scene, row0, row1, rowList) {
     // A6: recursion, reflect before refract (main.js:268-278)
     let reR = 0, reG = 0, reB = 0, rfR = 0, rfG = 0, rfB = 0;
     if (rlen !== 0) {
-      trace(segs - 1, lvl + 1, hx, hy, hz, rx, ry, rz);
+      trace(segs - 1, lvl + 1, 2 * path, hx, hy, hz, rx, ry, rz);
       reR = res[o + 3] * a3; reG = res[o + 4] * a3; reB = res[o + 5] * a3;
     }
     if (flen !== 0) {
-      trace(segs - 1, lvl + 1, hx, hy, hz, fx, fy, fz);
+      trace(segs - 1, lvl + 1, 2 * path + 1, hx, hy, hz, fx, fy, fz);
       rfR = res[o + 3] * a4; rfG = res[o + 4] * a4; rfB = res[o + 5] * a4;
     }
     // A7: lighting and shadows (main.js:280-318)
@@ -193,6 +200,10 @@ function renderPlain(w, h, scene, row0, row1, rowList) {
       const y = max(0, ceil(v * TH[ti]) - 1);
       const i = (y * W + x) * 4;
       cr = texels[i] / 255; cg = texels[i + 1] / 255; cb = texels[i + 2] / 255;
+    } else if (kind === 3) {
+      let c = starUniform(path);
+      c = (c >= FU[hi]) ? 0 : c * FV[hi];              // main.js:137-138
+      cr = c; cg = c; cb = c;
     } else {
       const u = atan2(-ny, -nx) / PI / 2 + 0.5;       // main.js:127
       const v = asin(-nz) / HALF_PI / 2 + 0.5;        // main.js:128
@@ -223,7 +234,8 @@ function renderPlain(w, h, scene, row0, row1, rowList) {
       let rx = tx - cox, ry = ty - coy, rz = tz - coz;
       const l = sqrt(rx * rx + ry * ry + rz * rz);
       if (l !== 0) { const s = 1 / l; rx = rx * s; ry = ry * s; rz = rz * s; }
-      trace(SEGS, 0, cox, coy, coz, rx, ry, rz);
+      { const pix = y * w + x; pixLo = pix >>> 0; pixHi = Math.floor(pix / 4294967296); }
+      trace(SEGS, 0, 1, cox, coy, coz, rx, ry, rz);
       out[i++] = 255 * res[0]; out[i++] = 255 * res[1]; out[i++] = 255 * res[2]; out[i++] = 255;
     }
   }

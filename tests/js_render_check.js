@@ -30,7 +30,7 @@ function maxDiff(a, b) { let m = 0; if (a.length !== b.length) return 999; for (
   const c = rt.render(h8.w, h8.h, load('h8'), {count: true});
   out.counted = {rays: c.stats.rays, pixels: c.stats.pixels};
   let threw = '';
-  try { const s = load('cfg1'); s.objects[0].mtl.sampler = {kind: 3}; rt.render(8, 8, s); } catch (e) { threw = e.message; }
+  try { const s = load('cfg1'); s.objects[0].mtl.sampler = {kind: 9}; rt.render(8, 8, s); } catch (e) { threw = e.message; }
   out.unsupported = threw;
   rt.shutdown();
   console.log(JSON.stringify(out));

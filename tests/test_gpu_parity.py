@@ -378,3 +378,25 @@ def test_general_cameras(lib, org, tgt, up, fov):
         blob = rt_host.flatten_scene(s)
         w, h = 160, 96
         assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1, name
+
+
+def test_hashed_stars_sampler(lib):
+    """Sampler kind 3 (main.js:135-139 with a counter-based hash for Math.random()): GPU == C restatement, in the
+    general kernel (the reference's 14-sphere scene), in the chain kernel (H8 with a starry sky) and with
+    supersampling; and because the hash is keyed by the sample's index in the FRAME, a frame rendered as tiles has the
+    same stars as the frame rendered at once."""
+    s14 = rt_host.load_scene("default14_stars")
+    blob = rt_host.flatten_scene(s14)
+    w, h = 320, 180
+    whole = gpu_frame(lib, blob, w, h)
+    assert ou.max_lsb(whole, ou.c_oracle_render(blob, w, h))[0] <= 1
+    assert ou.max_lsb(gpu_frame(lib, blob, w, h, STRICT), whole)[0] <= 1
+    assert whole != gpu_frame(lib, rt_host.flatten_scene(rt_host.load_scene("default14")), w, h)     # there ARE stars
+    band = gpu_tiles(lib, blob, w, h, (20, 3, 1, 1))                                                   # rows 60..79
+    assert band == whole[60 * w * 4:80 * w * 4]
+    sky_stars = {"kind": 3, "threshold": 0.01, "scale": 100.0}
+    for name in ("h8", "lcg64"):
+        s = rt_host.load_scene(name)
+        next(o for o in s["objects"] if o["r2"] == 25000000.0)["mtl"]["sampler"] = sky_stars
+        b = rt_host.flatten_scene(s)
+        assert ou.max_lsb(gpu_frame(lib, b, 200, 120), ou.c_oracle_render(b, 200, 120))[0] <= 1, name

@@ -14,7 +14,7 @@ import rt_host
 
 ROOT = ou.ROOT
 needs_node = pytest.mark.skipif(ou.node_path() is None, reason="node not installed")
-SCENE_NAMES = ["cfg1", "cfg2", "h8", "h8_d8", "default14", "lcg64", "lcg64_ss1"]
+SCENE_NAMES = ["cfg1", "cfg2", "h8", "h8_d8", "default14", "default14_stars", "lcg64", "lcg64_ss1"]
 
 
 def test_library_exports_every_declared_symbol(built):
@@ -61,8 +61,8 @@ def test_validate_rejects_bad_blobs(built):
     check(lambda b: struct.pack_into("<I", b, 160, 99), -1, "segs")
     check(lambda b: struct.pack_into("<I", b, 168, 0), -1, "n_objects")
     check(lambda b: struct.pack_into("<Q", b, 184, len(b) - 8), -1, "object table")
-    # sampler kind 3 = the reference's Math.random stars sampler: explicit error, not silence
-    check(lambda b: struct.pack_into("<i", b, 208 + 176, 3), -2, "stars sampler")
+    # an unknown sampler kind is an explicit error, not silence
+    check(lambda b: struct.pack_into("<i", b, 208 + 176, 7), -2, "sampler kind 7")
     check(lambda b: struct.pack_into("<i", b, 208 + 0 * 192 + 180, 9), -1, "texture index")
     buf = C.create_string_buffer(bytes(good[:100]), 100)
     assert lib.rt_scene_validate(buf, 100) == -1
@@ -79,8 +79,8 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
 
 def test_python_host_rejects_unsupported_sampler():
     s = rt_host.load_scene("cfg1")
-    s["objects"][0]["mtl"]["sampler"] = {"kind": 3}
-    with pytest.raises(ValueError, match="stars"):
+    s["objects"][0]["mtl"]["sampler"] = {"kind": 9}
+    with pytest.raises(ValueError, match="unsupported sampler kind"):
         rt_host.flatten_scene(s)
 
 

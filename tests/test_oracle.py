@@ -104,3 +104,25 @@ def test_restatement_bit_exact_vs_live_reference(scene, w, h):
     a = ou.node_cli("reference", ou.scene_json(scene), w, h)
     b = ou.node_cli("restate", ou.scene_json(scene), w, h)
     assert a["sha256"] == b["sha256"]
+
+
+# ---------------------------------------------------------------- hashed stars sampler (kind 3)
+@needs_node
+def test_stars_sampler_js_and_c_restatements_agree(built, tmp_path):
+    """main.js:135-139 draws its stars with Math.random(), so there is no reference frame to compare with: parity of
+    this sampler is UNPINNED against the reference by construction.  What is pinned is that the counter-based hash
+    that replaces Math.random() gives the same stars in every implementation here, and that they look right
+    (about 0.1 % of the sky's samples, grey)."""
+    w, h = 320, 180
+    out = tmp_path / "stars.rgba"
+    ou.node_cli("restate", ou.scene_json("default14_stars"), w, h, "--out", out)
+    js = np.fromfile(out, dtype=np.uint8)
+    blob = rt_host.flatten_scene(rt_host.load_scene("default14_stars"))
+    c = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8)
+    assert ou.max_lsb(js, c)[0] <= 1
+    black = np.frombuffer(ou.c_oracle_render(rt_host.flatten_scene(rt_host.load_scene("default14")), w, h), dtype=np.uint8)
+    diff = (c.reshape(-1, 4)[:, :3] != black.reshape(-1, 4)[:, :3]).any(axis=1)
+    stars = c.reshape(-1, 4)[diff]
+    assert 5 <= len(stars) <= 120                                  # ~0.001 of the sky samples (direct and reflected)
+    direct = stars[(stars[:, 0] == stars[:, 1]) & (stars[:, 1] == stars[:, 2])]
+    assert len(direct) >= 3                                        # stars seen directly are grey (c, c, c)
