@@ -242,6 +242,9 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
 template <bool REFRACT> struct frame;
 template <> struct frame<false> { double amb[3], ds[3], a3; };
 template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3]; int has_f, phase; };
+// A parked two-child node of the product general kernel: its own terms, its refraction ray, and the map F that
+// was accumulated above it (S, O, LO, HI), to be restored when its reflection subtree has been evaluated.
+struct park { double amb[3], ds[3], a3, a4, h[3], f[3], S, O[3], LO[3], HI[3]; uint32_t path, segs_left; int level, map_valid; };
 
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
@@ -257,9 +260,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #if RT_STRICT
   constexpr bool FOLD_FORWARD = false;
 #else
-  constexpr bool FOLD_FORWARD = !REFRACT;   // reflection-only scenes: no stack at all (see the descend step)
+  constexpr bool FOLD_FORWARD = true;       // the recursion is folded on the way down (see the descend step)
 #endif
   [[maybe_unused]] frame<REFRACT> stack[FOLD_FORWARD ? 1 : RT_MAX_SEGS];
+  // product general kernel: nodes with BOTH a reflection and a refraction child are parked here while their
+  // reflection subtree is traced (everything else needs no stack)
+  [[maybe_unused]] park parked[(FOLD_FORWARD && REFRACT) ? RT_MAX_SEGS : 1];
+  [[maybe_unused]] int sp = 0;
+  [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
   [[maybe_unused]] uint32_t tree_path = 1u;            // general kernel: position in the ray tree (root 1, reflect 2p, refract 2p+1)
 #ifdef RT_ABLATE_BOUNCE
@@ -588,38 +596,55 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #pragma unroll
           for (int c = 0; c < 3; c++) ret[c] = maxa(col[c] * a0, min1(col[c] * diffuse + col[c] * specular));
         } else if constexpr (FOLD_FORWARD) {
-          // Reflection-only recursion is a chain, and each level maps its child's colour x through
-          //   f(x) = max(amb, min(1, ds + a3*x))            (main.js:326-336)
-          // a non-decreasing clamped-affine map.  Compositions of such maps are again clamped-affine, so the
-          // pixel as a function of the ray currently being traced is kept in closed form
-          //   F(x) = max(LO, min(HI, O + S*x))              (S one scalar; O, LO, HI per channel)
-          // and updated on the way DOWN: no stack, no unwinding, any depth.  The ten doubles live in LDS
-          // (lane-major, conflict-free) so they cost no registers; they are touched once per bounce.
-          //   F o f:  S' = S*a3,  O' = O + S*ds,  LO' = clampF(O + S*amb),  HI' = clampF(O + S*max(amb,1))
+          // Each level maps its child's colour x through  f(x) = max(amb, min(1, (ds [+ other child]) + a*x))
+          // (main.js:326-336), a non-decreasing clamped-affine map, and compositions of such maps are again
+          // clamped-affine.  So the pixel, as a function of the colour of the ray currently being traced, is kept in
+          // closed form  F(x) = max(LO, min(HI, O + S*x))  (S one scalar; O, LO, HI per channel) and updated on the
+          // way DOWN: a node with ONE child (reflection-only or refraction-only: mirrors, metals, glass) needs no
+          // stack and no unwinding at any depth.  The ten doubles live in LDS (lane-major, conflict-free), touched
+          // once per bounce.   F o f:  S' = S*a,  O' = O + S*ds,  LO' = clampF(O + S*amb),  HI' = clampF(O + S*max(amb,1))
+          // A node with BOTH children (a bubble) is parked with the map accumulated so far, its reflection subtree is
+          // traced under a fresh (identity) map, and when that subtree's colour is known the node continues as a
+          // one-child node through its refraction ray (main.js:268-278: reflection is evaluated before refraction).
           const uint32_t T = RT_WG_THREADS;
-          if (level == 0) {
-            acc[0] = a3;
+          double A[3], D[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const double A = col[c] * a0;
-              acc[(1 + c) * T] = col[c] * diffuse + col[c] * specular;
-              acc[(4 + c) * T] = A;
-              acc[(7 + c) * T] = __builtin_fmax(A, 1.0);
+          for (int c = 0; c < 3; c++) { A[c] = col[c] * a0; D[c] = col[c] * diffuse + col[c] * specular; }
+          const bool via_f = REFRACT && !go_r;                          // the only child is the refraction ray
+          if (REFRACT && go_r && go_f) {
+            park &pk = parked[sp++];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { pk.amb[c] = A[c]; pk.ds[c] = D[c]; }
+            pk.a3 = a3; pk.a4 = a4; pk.h[0] = h.x; pk.h[1] = h.y; pk.h[2] = h.z; pk.f[0] = f.x; pk.f[1] = f.y; pk.f[2] = f.z;
+            pk.path = tree_path; pk.segs_left = segs_left; pk.level = level; pk.map_valid = map_valid;
+            if (map_valid) {
+              pk.S = acc[0];
+#pragma unroll
+              for (int c = 0; c < 3; c++) { pk.O[c] = acc[(1 + c) * T]; pk.LO[c] = acc[(4 + c) * T]; pk.HI[c] = acc[(7 + c) * T]; }
             }
+            map_valid = false;
+            p = h; d = r; tree_path = 2u * tree_path;
           } else {
-            const double S = acc[0];
+            const double coef = via_f ? a4 : a3;
+            if (!map_valid) {
+              acc[0] = coef;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const double A = col[c] * a0, D = col[c] * diffuse + col[c] * specular;
-              const double O = acc[(1 + c) * T], LO = acc[(4 + c) * T], HI = acc[(7 + c) * T];
-              const double l2 = __builtin_fma(S, A, O), h2 = __builtin_fma(S, __builtin_fmax(A, 1.0), O);
-              acc[(1 + c) * T] = __builtin_fma(S, D, O);
-              acc[(4 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, l2));
-              acc[(7 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, h2));
+              for (int c = 0; c < 3; c++) { acc[(1 + c) * T] = D[c]; acc[(4 + c) * T] = A[c]; acc[(7 + c) * T] = __builtin_fmax(A[c], 1.0); }
+            } else {
+              const double S = acc[0];
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                const double O = acc[(1 + c) * T], LO = acc[(4 + c) * T], HI = acc[(7 + c) * T];
+                const double l2 = __builtin_fma(S, A[c], O), h2 = __builtin_fma(S, __builtin_fmax(A[c], 1.0), O);
+                acc[(1 + c) * T] = __builtin_fma(S, D[c], O);
+                acc[(4 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, l2));
+                acc[(7 + c) * T] = __builtin_fmax(LO, __builtin_fmin(HI, h2));
+              }
+              acc[0] = S * coef;
             }
-            acc[0] = S * a3;
+            map_valid = true;
+            p = h; d = via_f ? f : r; tree_path = 2u * tree_path + (via_f ? 1u : 0u);
           }
-          p = h; d = r;
           level++; segs_left--;
           descend = true;
         } else {
@@ -641,14 +666,45 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       if (descend) continue;
 
       if constexpr (FOLD_FORWARD) {
-        // the chain ended with colour `ret`: apply the accumulated map once
-        if (level > 0) {
-          const uint32_t T = RT_WG_THREADS;
+        // a chain of one-child nodes ended with colour `ret`: apply the accumulated map once
+        const uint32_t T = RT_WG_THREADS;
+        if (map_valid) {
           const double S = acc[0];
 #pragma unroll
           for (int c = 0; c < 3; c++) ret[c] = __builtin_fmax(acc[(4 + c) * T], __builtin_fmin(acc[(7 + c) * T], __builtin_fma(S, ret[c], acc[(1 + c) * T])));
         }
-        break;
+        bool resumed = false;
+        if constexpr (REFRACT) {
+          if (sp > 0) {
+            // `ret` is the colour of a parked node's reflection child: fold it into the node's constant term, put the
+            // map that was accumulated above the node back, and go on through the node's refraction ray
+            const park &pk = parked[--sp];
+            const double coef = pk.a4;
+            if (!pk.map_valid) {
+              acc[0] = coef;
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                acc[(1 + c) * T] = pk.ds[c] + ret[c] * pk.a3; acc[(4 + c) * T] = pk.amb[c]; acc[(7 + c) * T] = __builtin_fmax(pk.amb[c], 1.0);
+              }
+            } else {
+              const double S = pk.S;
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                const double Dn = pk.ds[c] + ret[c] * pk.a3;
+                const double l2 = __builtin_fma(S, pk.amb[c], pk.O[c]), h2 = __builtin_fma(S, __builtin_fmax(pk.amb[c], 1.0), pk.O[c]);
+                acc[(1 + c) * T] = __builtin_fma(S, Dn, pk.O[c]);
+                acc[(4 + c) * T] = __builtin_fmax(pk.LO[c], __builtin_fmin(pk.HI[c], l2));
+                acc[(7 + c) * T] = __builtin_fmax(pk.LO[c], __builtin_fmin(pk.HI[c], h2));
+              }
+              acc[0] = S * coef;
+            }
+            map_valid = true;
+            p = mk(pk.h[0], pk.h[1], pk.h[2]); d = mk(pk.f[0], pk.f[1], pk.f[2]);
+            tree_path = 2u * pk.path + 1u; segs_left = pk.segs_left - 1u; level = pk.level + 1;
+            resumed = true;
+          }
+        }
+        if (!resumed) break;
       } else {
         // ---------------- return `ret` to the parents (post-order fold, main.js:268-278, :326-336) ----------------
         bool resumed = false;
