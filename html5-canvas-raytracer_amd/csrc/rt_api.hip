@@ -433,7 +433,8 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.cull = gt + 2 * (size_t)hd.n_objects;
   L.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
   // the grids are built for the product kernel's order: B if the scene has an enclosing sphere, else the scene's own
-  L.shadow_grid = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && getenv("RT_NO_SHADOW_GRID") == nullptr) ? s->d_shadow_grid : nullptr;
+  static const bool no_grid = getenv("RT_NO_SHADOW_GRID") != nullptr;     // A/B switch for the profiles/ scripts
+  L.shadow_grid = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && !no_grid) ? s->d_shadow_grid : nullptr;
   L.geom_light = gt + 3 * (size_t)hd.n_objects;
   L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
   L.enclosing = order_b ? hd.n_objects - 1 : ~0u;
@@ -708,7 +709,7 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
   } else {
     // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
     //      GPU stores its tiles contiguously, ONE RCCL gather to GPU 0 over xGMI, one de-interleave pass ----
-    if ((rc = ensure_rccl(ndev))) return rc;
+    if ((rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
     const uint32_t tile_rows = (h >= (uint32_t)ndev * 64u) ? 16u : RT_TILE_H;
     const uint32_t n_tiles_total = (h + tile_rows - 1) / tile_rows;
     const uint32_t tiles_per_rank = (n_tiles_total + ndev - 1) / ndev;
@@ -719,15 +720,16 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
       rc = rt_scene_upload(g, blob, bytes, &scenes[g]);
       if (!rc) rc = ensure_frame(G.dev[g], band_bytes);
     }
-    if (!rc) {
+    if (!rc) {                                   // (no early returns below: the scenes are freed at the end)
       device_state &R = G.dev[0];
-      HIP_TRY(hipSetDevice(R.hip_id));
-      if (R.gather_bytes < band_bytes * ndev + frame_bytes) {
+      hipError_t e = hipSetDevice(R.hip_id);
+      if (e == hipSuccess && R.gather_bytes < band_bytes * ndev + frame_bytes) {
         if (R.d_gather) (void)hipFree(R.d_gather);
         R.d_gather = nullptr; R.gather_bytes = 0;
-        HIP_TRY(hipMalloc(&R.d_gather, band_bytes * ndev + frame_bytes));
-        R.gather_bytes = band_bytes * ndev + frame_bytes;
+        e = hipMalloc(&R.d_gather, band_bytes * ndev + frame_bytes);
+        if (e == hipSuccess) R.gather_bytes = band_bytes * ndev + frame_bytes;
       }
+      if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "gather buffer: %s", hipGetErrorString(e));
     }
     std::vector<hipEvent_t> ev0(ndev, nullptr), ev1(ndev, nullptr);
     for (int g = 0; g < ndev && !rc; g++) {
