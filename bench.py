@@ -43,12 +43,12 @@ FRAME_W, FRAME_H = 3840, 2160
 def cpu_baseline(scene_name, w, h):
     """Oracle leg (checker code, timed beside the GPU; never on the product path)."""
     import oracle_util as ou
-    rows = min(h, 1080)
+    rows, reps = h, 4              # whole frames, ~10 s of single-thread CPU work at ~4 Mpixel/s
     if ou.node_path():
-        r = ou.node_cli("time", ou.scene_json(scene_name), w, h, rows, timeout=900)
+        r = ou.node_cli("time", ou.scene_json(scene_name), w, h, rows, reps, timeout=900)
         return {"value": round(r["mpixel_per_s"], 4), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-                "sample": "%d of %d rows evenly spaced (%d pixels), oracle/restate.js (bit-identical to main.js) under node %s, 1 thread, "
-                          "after an untimed JIT warm-up pass" % (rows, h, r["pixels"], r["node"]),
+                "sample": "%d whole %dx%d frames (%d pixels, %.1f s), oracle/restate.js (bit-identical to main.js) under node %s, 1 thread, "
+                          "after an untimed JIT warm-up pass over a quarter of the rows" % (reps, w, h, r["pixels"], r["ms"] / 1e3, r["node"]),
                 "mray_per_s": round(r["rays"] / r["ms"] / 1e3, 4), "host_cpus": os.cpu_count()}
     import rt_host
     blob = rt_host.flatten_scene(rt_host.load_scene(scene_name))

@@ -6,7 +6,7 @@
 //   node oracle/cli.js reference <scene.json> <w> <h> [row0 row1] [--out f.rgba]   /root/reference/main.js (build container only)
 //   node oracle/cli.js main      <w> <h> [--out f.rgba]                            the reference's own main()
 //   node oracle/cli.js flatten   <scene.json> --out f.blob                         js/flatten.js blob (host-logic parity with Python)
-//   node oracle/cli.js time      <scene.json> <w> <h> <rows>                       warm-up + timed restatement of <rows> rows (1 thread)
+//   node oracle/cli.js time      <scene.json> <w> <h> <rows> [reps]                warm-up + timed restatement of <rows> rows, reps times (1 thread)
 // Prints one JSON line with sha256 / counters / timings.
 
 const fs = require('fs');
@@ -59,13 +59,15 @@ if (cmd === 'restate' || cmd === 'reference') {
   const scene = loadScene(args[1]);
   const w = +args[2], h = +args[3], rows = Math.min(+args[4], h);
   const R = require('./restate.js');
+  const reps = Math.max(1, +(args[5] || 1));
   const list = []; for (let k = 0; k < rows; k++) list.push(Math.min(h - 1, Math.floor((k + 0.5) * h / rows)));
   R.render(w, h, scene, {rows: list.filter((_, k) => k % 4 === 0)});
   const t0 = process.hrtime.bigint();
-  const r = R.render(w, h, scene, {rows: list});
+  let r;
+  for (let i = 0; i < reps; i++) r = R.render(w, h, scene, {rows: list});
   const ms = Number(process.hrtime.bigint() - t0) / 1e6;
-  emit({cmd, w, h, rows, sample: 'evenly spaced rows', pixels: r.pixels, ms, mpixel_per_s: r.pixels / ms / 1e3, rays: r.rays, shadowRays: r.shadowRays,
-    sphereTests: r.sphereTests, node: process.version, threads: 1});
+  emit({cmd, w, h, rows, reps, sample: 'evenly spaced rows', pixels: r.pixels * reps, ms, mpixel_per_s: r.pixels * reps / ms / 1e3, rays: r.rays * reps,
+    shadowRays: r.shadowRays * reps, sphereTests: r.sphereTests * reps, node: process.version, threads: 1});
 } else {
   console.error('usage: see header of oracle/cli.js');
   process.exit(2);
