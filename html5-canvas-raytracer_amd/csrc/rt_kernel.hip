@@ -424,24 +424,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           col[0] = col[1] = col[2] = c;
         } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
 
-        // A4 reflection direction
-        v3 r = mk(0, 0, 0); double rlen = 0.0;
-        // (with segs_left == 1 the child returns [0,0,0] at main.js:221 whatever its direction: skip it)
-        if (a3 > 0.0 && segs_left > 1) r = unit(reflect(d, n), &rlen);
-        // A5 refraction direction
-        v3 f = mk(0, 0, 0); double flen = 0.0;
-        if (REFRACT && a4 > 0.0 && segs_left > 1) {
-          const double dn = dot(d, n);
-          double cosi = -((dn < -1.0) ? -1.0 : min1(dn));              // -Math.max(-1, Math.min(1, dot))
-          v3 nn = n; double eta;
-          if (cosi < 0.0) { cosi = -cosi; nn = mk(-n.x, -n.y, -n.z); eta = m.refract_index; }
-          else eta = rt_rcp(m.refract_index);
-          const double k = 1.0 - eta * eta * (1.0 - cosi * cosi);
-          if (k > 0.0) {
-            const double q = eta * cosi - rt_sqrt(k);
-            f = mk(d.x * eta + nn.x * q, d.y * eta + nn.y * q, d.z * eta + nn.z * q);
-          } else f = reflect(d, nn);                                   // total internal reflection
-          f = unit(f, &flen);
+        // general product kernel: the sampled colour waits in LDS (slots 10-12 of the lane's fold state) while the
+        // lights are scanned: six registers fewer across the hottest loop, which is what lets this kernel fit
+        // 96 VGPRs = 5 waves per SIMD
+        if constexpr (FOLD_FORWARD && REFRACT) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[(10 + c) * RT_WG_THREADS] = col[c];
         }
 
         // A7 lighting and shadows
@@ -589,6 +577,37 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           specular = min1(specular) * a2;
         }
 
+        // A4 reflection direction.  (Computed AFTER the lighting: in program order the reference does it before, but it
+        // is pure, and placed here neither r nor f — nor n, which is l with its sign restored — occupies registers
+        // across the shadow scans, the hottest loop of the kernel.)
+#if RT_STRICT
+        const v3 nq = n;
+#else
+        const v3 nq = inside ? mk(-l.x, -l.y, -l.z) : l;
+#endif
+        v3 r = mk(0, 0, 0); double rlen = 0.0;
+        // (with segs_left == 1 the child returns [0,0,0] at main.js:221 whatever its direction: skip it)
+        if (a3 > 0.0 && segs_left > 1) r = unit(reflect(d, nq), &rlen);
+        // A5 refraction direction
+        v3 f = mk(0, 0, 0); double flen = 0.0;
+        if (REFRACT && a4 > 0.0 && segs_left > 1) {
+          const double dn = dot(d, nq);
+          double cosi = -((dn < -1.0) ? -1.0 : min1(dn));              // -Math.max(-1, Math.min(1, dot))
+          v3 nn = nq; double eta;
+          if (cosi < 0.0) { cosi = -cosi; nn = mk(-nq.x, -nq.y, -nq.z); eta = m.refract_index; }
+          else eta = rt_rcp(m.refract_index);
+          const double k = 1.0 - eta * eta * (1.0 - cosi * cosi);
+          if (k > 0.0) {
+            const double q = eta * cosi - rt_sqrt(k);
+            f = mk(d.x * eta + nn.x * q, d.y * eta + nn.y * q, d.z * eta + nn.z * q);
+          } else f = reflect(d, nn);                                   // total internal reflection
+          f = unit(f, &flen);
+        }
+
+        if constexpr (FOLD_FORWARD && REFRACT) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) col[c] = acc[(10 + c) * RT_WG_THREADS];
+        }
         const bool go_r = (rlen != 0.0);
         const bool go_f = REFRACT && (flen != 0.0);
         if (!go_r && !go_f) {
@@ -760,7 +779,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const rt_sphere *mtl = (const rt_sphere *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
   const rt_geom *cull = (const rt_geom *)(lds_raw + mtl_words + tex_words);
-  double *acc = lds_raw + mtl_words + tex_words + cull_words + tid;   // 10 x RT_WG_THREADS doubles, lane-major (product chain kernel only)
+  double *acc = lds_raw + mtl_words + tex_words + cull_words + tid;   // fold state: 10 (general kernel: 13) x RT_WG_THREADS doubles, lane-major
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
