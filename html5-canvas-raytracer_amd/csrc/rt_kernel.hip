@@ -176,6 +176,7 @@ __device__ __forceinline__ double star_uniform(uint32_t pix_lo, uint32_t pix_hi,
 
 // ECMAScript ToInt32(x) & 1   (main.js:129-130)
 __device__ __forceinline__ int to_int32_bit0(double x) {
+  if (fabs(x) < 2147483648.0) return (int)x & 1;     // the common case: one truncating conversion
   if (!(fabs(x) < RT_INF)) return 0;                 // NaN, +-Infinity -> 0
   double t = trunc(x);
   if (fabs(t) >= 4294967296.0) t = t - floor(t / 4294967296.0) * 4294967296.0;

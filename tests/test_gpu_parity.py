@@ -416,3 +416,16 @@ def test_full_size_frame_vs_bit_exact_js_restatement(lib, scene, w, h, tmp_path)
     worst, frac = ou.max_lsb(gpu_frame(lib, rt_host.load_scene(scene), w, h), want)
     assert worst <= 1, (scene, worst)
     assert frac < 0.002, (scene, frac)                                # SURVEY: ~0.04 % of channels sit on exact .5 ties
+
+
+def test_checker_toint32_beyond_32_bits(lib):
+    """(u * freq) & 1 is ECMAScript ToInt32 (main.js:129-130): modulo 2^32 for huge products, 0 for non-finite ones.
+    Frequencies that push u*freq past 2^31 and 2^32, or far beyond 2^53 (every such double is even), take the kernel's
+    slow path.  (Frequencies between ~1e11 and 2^53 are left out on purpose: there the parity depends on the last ulp
+    of atan2/asin, which differs between any two maths libraries, V8's and glibc's included.)"""
+    for fu, fv in [(3.0e9, 7.0e9), (1e308, -1e308), (-5000.0, 2500.0)]:
+        s = rt_host.load_scene("h8")
+        home = next(o for o in s["objects"] if o["mtl"]["sampler"]["kind"] == 2)
+        home["mtl"]["sampler"]["freqU"], home["mtl"]["sampler"]["freqV"] = fu, fv
+        blob = rt_host.flatten_scene(s)
+        assert ou.max_lsb(gpu_frame(lib, blob, 160, 90), ou.c_oracle_render(blob, 160, 90))[0] <= 1, (fu, fv)
