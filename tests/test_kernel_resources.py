@@ -1,0 +1,58 @@
+"""Build-time guard on the register budget of the product kernels (CPU test: reads the gfx950 code object).
+
+DESIGN.md §4: the trace kernel runs at 5 waves/SIMD, which needs <= 96 VGPRs (512 / 5 rounded down to the
+allocation granule of 8); 97 registers silently costs a wave and about 10 % of the headline rate, and a spill
+shows up as scratch traffic.  The numbers come from the code object's own metadata notes, so the check needs
+only the LLVM tools that ship with ROCm.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "html5-canvas-raytracer_amd", "csrc")
+TOOLS = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+
+pytestmark = pytest.mark.skipif(not all(os.path.exists(t) for t in TOOLS), reason="ROCm LLVM tools not installed")
+
+
+def kernel_notes(obj, tmp_path):
+    fat, co = tmp_path / "k.bin", tmp_path / "k.co"
+    subprocess.run([TOOLS[0], "--dump-section", ".hip_fatbin=%s" % fat, obj], check=True)
+    subprocess.run([TOOLS[1], "--unbundle", "--type=o", "--input=%s" % fat,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=%s" % co], check=True)
+    text = subprocess.run([TOOLS[2], "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    kernels, cur = {}, None
+    # one metadata map per kernel; .name comes in the middle of it, so gather by the "- .agpr_count" record start
+    for block in re.split(r"\n\s+- \.agpr_count:", text)[1:]:
+        f = dict(re.findall(r"\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|"
+                            r"group_segment_fixed_size|max_flat_workgroup_size):\s+(\S+)", block))
+        m = re.search(r"rt_traceILb([01])ELb([01])ELb([01])ELb([01])E", f.get("name", ""))
+        if m:
+            kernels[tuple(int(x) for x in m.groups())] = {k: int(v) for k, v in f.items() if k != "name"}
+    return kernels
+
+
+def test_product_kernels_fit_five_waves(built, tmp_path):
+    k = kernel_notes(os.path.join(CSRC, "rt_kernel_fast.o"), tmp_path)
+    # <REFRACT, COUNT, SS2, GRID>: 8 product instantiations + 4 counting ones
+    assert len(k) == 12
+    for (refract, count, ss2, grid), r in k.items():
+        assert r["vgpr_spill_count"] == 0, (refract, count, ss2, grid, r)
+        assert r["max_flat_workgroup_size"] == 256
+        if count:
+            continue                                  # the counting kernels are a test aid, not a product path
+        assert r["vgpr_count"] <= 96, (refract, count, ss2, grid, r)
+        # chain scenes keep their fold state in LDS and need no scratch; the general kernel's only private memory is
+        # the explicit two-child park stack
+        if not refract:
+            assert r["private_segment_fixed_size"] == 0, (refract, count, ss2, grid, r)
+
+
+def test_strict_kernels_do_not_spill(built, tmp_path):
+    k = kernel_notes(os.path.join(CSRC, "rt_kernel_strict.o"), tmp_path)
+    assert k, "no rt_trace instantiations found in the strict object"
+    for key, r in k.items():
+        assert r["vgpr_spill_count"] == 0, (key, r)
