@@ -15,7 +15,9 @@ tiles of all N frames in one launch (rt_render_batch_device), ONE all-to-all sen
 rank f, and each rank de-interleaves one whole frame in its own HBM.  Per-GPU work per step is one frame's
 worth of pixels at every N (weak scaling), every frame is reassembled by a single RCCL collective, and the
 collective uses all N(N-1) directed xGMI links at once (a gather to one root would be bound by that
-root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels, three links' worth).  The
+root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels, three links' worth).  The bands
+cross the links as RGB24 — the alpha byte is the constant 255 (main.js:198) and is restored by the
+de-interleave — which takes a quarter off the link time that bounds N=2 and N=4.  The
 exchange of step k overlaps the render of step k+1 (two buffer slots).  The scene is resident in HBM
 before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
 
@@ -106,7 +108,12 @@ def main():
     renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
     flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
 
-    plan = shard.TilePlan(w, h, TILE_ROWS, world)
+    # N>1: the bands cross xGMI as RGB24 (the alpha byte is the constant 255, main.js:198; the de-interleave on the
+    # receiving rank restores it) — a quarter less link time, which is what bounds N=2 and N=4.
+    # RT_BENCH_RGBA_EXCHANGE=1 ships RGBA8 instead (A/B).
+    channels = 3 if (world > 1 and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+    plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
+    batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
     # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
     tstream = torch.cuda.Stream(device=dev)
@@ -123,9 +130,9 @@ def main():
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
     if world > 1:
-        send = [torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
-        host_recv = torch.empty((world, plan.band_rows, w, 4), dtype=torch.uint8) if rehearse else None
+        send = [torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_recv = torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8) if rehearse else None
     pending = []      # (work, slot) of exchanges in flight; at most 2
     # the wait for an exchange and the de-interleave that follows run on a SIDE stream, so the render stream
     # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
@@ -136,7 +143,7 @@ def main():
         if world == 1:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
         else:   # this rank's tiles of all `world` frames of the batch, one launch
-            renderer.render_batch(w, h, send[slot].data_ptr(), my_tiles, world, plan.band_bytes, stream=stream, flags=flags)
+            renderer.render_batch(w, h, send[slot].data_ptr(), my_tiles, world, plan.band_bytes, stream=stream, flags=batch_flags)
 
     def finish(slot_work):
         work, slot = slot_work
@@ -224,7 +231,7 @@ def main():
         total_pixels = w * h * frames_per_step * args.steps
         value = total_pixels / elapsed / 1e6
         flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
-        algo_bytes = 4.0 * launch_pixels
+        algo_bytes = float(channels) * launch_pixels        # what one launch stores: RGBA8, or RGB24 bands at N>1
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -237,7 +244,8 @@ def main():
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
         else:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
-                   "reassembles frame f on rank f, de-interleave in HBM; exchange of step k overlaps render of step k+1" % (world, TILE_ROWS, world))
+                   "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; exchange of step k overlaps render of step k+1"
+                   % (world, TILE_ROWS, world, "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8"))
         out = {
             "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -251,14 +259,14 @@ def main():
             "max_lsb_vs_reference_rows": max_lsb,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "4 B per output pixel (one RGBA8 store); the path is FP64-VALU bound, see fp64_valu"},
+                         "note": "%d B per output pixel (one %s store); the path is FP64-VALU bound, see fp64_valu" % (channels, "RGBA8" if channels == 4 else "RGB24")},
             "fp64_valu": {"flop_per_pixel_model": round(flops_pp, 1), "achieved": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12, 3),
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
                           "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
         }
         if world > 1:
             out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
-                               "bytes_per_directed_link_per_step": plan.band_bytes}
+                               "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.scene, w, h)

@@ -411,6 +411,7 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   if (tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0) return fail(RT_ERR_INVALID, "empty tile set");
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows > (1ull << 24)) return fail(RT_ERR_INVALID, "too many rows in one call");
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows * w >= (1ull << 32)) return fail(RT_ERR_INVALID, "a call may cover at most 2^32 - 1 pixels per frame");
+  if ((flags & RT_FLAG_RGB24) && (w & 3u)) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 needs a frame width that is a multiple of 4 (got %u)", w);
   int rc = ensure_device(s->device);
   if (rc) return rc;
   device_state &D = G.dev[s->device];
@@ -461,6 +462,7 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   if ((uint64_t)tiles->n_tiles * L.rb_per_tile > 65535u) return fail(RT_ERR_INVALID, "%u tiles x %u row blocks exceed the grid's y limit (65535)", tiles->n_tiles, L.rb_per_tile);
   L.n_frames = n_frames;
   L.frame_stride = frame_stride_bytes / 4u;
+  L.rgb24 = (flags & RT_FLAG_RGB24) ? 1u : 0u;
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
@@ -594,6 +596,42 @@ extern "C" int rt_deinterleave_device(int device, const void *d_src, void *d_dst
   return RT_OK;
 }
 
+// RGB24 bands -> RGBA8 frame.  A work-item turns 3 source words (4 pixels x 3 bytes) into one uint4 (4 pixels x RGBA);
+// w % 4 == 0, so rows of both sides start word-aligned.
+__global__ void __launch_bounds__(256) rt_deinterleave_rgb24_kernel(const uint32_t *__restrict__ src, uint4 *__restrict__ dst, uint32_t row_quads,
+                                                                    uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_words) {
+  const uint32_t row = blockIdx.y;
+  const uint32_t tile = row / tile_rows, r = row - tile * tile_rows;
+  const uint32_t rank = tile % n_ranks, local_tile = tile / n_ranks;
+  const uint32_t *__restrict__ s = src + rank * rank_stride_words + ((uint64_t)local_tile * tile_rows + r) * row_quads * 3u;
+  uint4 *__restrict__ d = dst + (uint64_t)row * row_quads;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < row_quads; x += gridDim.x * blockDim.x) {
+    const uint32_t a = s[3u * x], b = s[3u * x + 1u], c = s[3u * x + 2u];
+    uint4 o;
+    o.x = a | 0xff000000u;
+    o.y = (a >> 24) | (b << 8) | 0xff000000u;
+    o.z = (b >> 16) | (c << 16) | 0xff000000u;
+    o.w = (c >> 8) | 0xff000000u;
+    d[x] = o;
+  }
+}
+
+extern "C" int rt_deinterleave_rgb24_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h, uint32_t tile_rows, uint32_t n_ranks,
+                                            uint64_t rank_stride_bytes, void *hip_stream) {
+  if (!d_src || !d_dst || !w || !h || !tile_rows || !n_ranks || (rank_stride_bytes & 3u) || (w & 3u) || (((uintptr_t)d_src) & 3u) || (((uintptr_t)d_dst) & 15u))
+    return fail(RT_ERR_INVALID, "bad RGB24 de-interleave arguments (w must be a multiple of 4, dst 16-byte aligned)");
+  if (h > 65535u) return fail(RT_ERR_INVALID, "de-interleave: more than 65535 rows");
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[device].stream;
+  const uint32_t row_quads = w / 4u;
+  const dim3 grid((row_quads + 255u) / 256u, h), block(256);
+  hipLaunchKernelGGL(rt_deinterleave_rgb24_kernel, grid, block, 0, stream, (const uint32_t *)d_src, (uint4 *)d_dst, row_quads, tile_rows, n_ranks,
+                     rank_stride_bytes / 4u);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------ RCCL (lazy)
 namespace {
 typedef int (*nccl_comm_init_all_t)(void **comms, int ndev, const int *devlist);
@@ -640,6 +678,7 @@ int ensure_frame(device_state &D, size_t bytes) {
 // ------------------------------------------------------------------------------------ render(width,height,scene)
 extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats) {
   if (!out_rgba) return fail(RT_ERR_INVALID, "out_rgba is NULL");
+  if (flags & RT_FLAG_RGB24) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 applies to the device entry points only; rt_render returns ImageData.data (RGBA8)");
   if (!G.inited) return fail(RT_ERR_STATE, "rt_init has not been called");
   std::lock_guard<std::mutex> lk(G.mu);
   const auto t_begin = std::chrono::steady_clock::now();

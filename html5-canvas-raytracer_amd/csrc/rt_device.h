@@ -50,10 +50,11 @@ struct rt_launch {
   uint32_t tiles_x;                  // workgroup tiles per row of the frame
   uint32_t rb_per_tile, rb_shift;    // workgroup row blocks per tile; log2 of it when a power of two, else ~0u
   uint32_t n_frames;                 // frames of the batch (grid z); frame f is written at out + f*frame_stride
-  uint64_t frame_stride;             // in pixels
+  uint64_t frame_stride;             // in 32-bit words (= pixels for RGBA8 output)
   uint32_t n_loop;                   // spheres the per-ray loops walk (n_objects, or n_objects-1 when `enclosing` is set)
   uint32_t enclosing;                // device index (== n_loop, the table's last entry) of a sphere that strictly contains
                                      // every other sphere, every light and the camera; ~0u if none or not used
+  uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
 };
 
 #endif

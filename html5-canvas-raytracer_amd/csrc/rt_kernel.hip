@@ -828,15 +828,34 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t frame_i = blockIdx.z;
   const bool valid = P1.valid;
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
-  if (!SS2) {
-    if (valid) (L.out + (size_t)frame_i * L.frame_stride)[P1.lrow * L.w + P1.px] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;   // a band holds < 2^32 pixels (host check)
-  } else {
-    // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields)
+  uint32_t *__restrict__ out = L.out + (size_t)frame_i * L.frame_stride;
+  uint32_t rgbw;                                       // this lane's pixel as 0x00BBGGRR
+  if (!SS2) rgbw = r8 | (g8 << 8) | (b8 << 16);
+  else {
+    // 2x2 box filter across the 4 lanes of a quad: (a+b+c+d+2)>>2 per channel (10-bit fields); all four lanes end
+    // up with the pixel
     uint32_t packed = r8 | (g8 << 10) | (b8 << 20);
     packed += __shfl_xor(packed, 1);
     packed += __shfl_xor(packed, 2);
-    const uint32_t R = ((packed & 1023u) + 2u) >> 2, G = (((packed >> 10) & 1023u) + 2u) >> 2, B = (((packed >> 20) & 1023u) + 2u) >> 2;
-    if (valid && P1.sub == 0u) (L.out + (size_t)frame_i * L.frame_stride)[P1.lrow * L.w + P1.px] = R | (G << 8) | (B << 16) | 0xff000000u;
+    rgbw = (((packed & 1023u) + 2u) >> 2) | ((((packed >> 10) & 1023u) + 2u) >> 2 << 8) | ((((packed >> 20) & 1023u) + 2u) >> 2 << 16);
+  }
+  if (!L.rgb24) {                                      // wave-uniform
+    if (valid && P1.sub == 0u) out[P1.lrow * L.w + P1.px] = rgbw | 0xff000000u;   // a band holds < 2^32 pixels (host check)
+  } else {
+    // RT_FLAG_RGB24: the 8 pixels a wave holds of one row are 24 bytes = 6 words.  Word j of the group takes its bytes
+    // from pixels p = j + j/3 and p + 1, shifted by (j mod 3) bytes; lanes j < 6 of the group store.  w % 4 == 0 (host
+    // check), so a group at the right edge holds 8 or 4 pixels = 6 or 3 whole words and rows start word-aligned.
+    const uint32_t lane2 = tid2 & 63u;
+    const uint32_t slot = SS2 ? lane2 >> 2 : lane2;    // pixel slot in the wave; a row's 8 slots are consecutive
+    const uint32_t j = slot & 7u, j3 = (j * 11u) >> 5; // j3 = j / 3 for j < 8
+    const uint32_t p = (slot & ~7u) + j + j3, sh = (j - 3u * j3) * 8u;
+    const uint32_t pn = (j < 6u) ? p + 1u : p;         // lanes 6,7 store nothing; keep their source lane inside the group
+    const uint32_t lo = __shfl(rgbw, SS2 ? (p << 2) : p), hi = __shfl(rgbw, SS2 ? (pn << 2) : pn);
+    const uint32_t word = (lo >> sh) | (hi << (24u - sh));
+    const uint32_t x0 = P1.px - j;                     // first pixel of the group (a multiple of 8)
+    const uint32_t in_row = (x0 + 8u <= L.w) ? 6u : ((x0 + 4u <= L.w) ? 3u : 0u);
+    const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h);
+    if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
   }
 
   if (COUNT) {

@@ -27,6 +27,7 @@ SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS = 0, 1, 2, 3
 
 RT_FLAG_COUNT = 1
 RT_FLAG_STRICT_FP = 2
+RT_FLAG_RGB24 = 4        # device entry points: 3 bytes per pixel, the constant alpha stays home (include/rt_hip.h)
 
 
 # --------------------------------------------------------------------------- scenes
@@ -155,6 +156,8 @@ ABI = {
     "rt_copy_to_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rt_deinterleave_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint64, C.c_void_p]),
+    "rt_deinterleave_rgb24_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_uint64, C.c_void_p]),
 }
 
 

@@ -11,7 +11,9 @@ Throughput form (what bench.py times): a step is a BATCH of `world` frames.  Eve
 tiles of all `world` frames (one launch, rt_render_batch_device), then ONE all-to-all sends the band of
 frame f to rank f, so each rank reassembles one whole frame per step.  On a point-to-point xGMI full mesh
 that uses every directed link at once (each carries 1/world of a frame), where a gather to a single root
-would funnel every band through the root's 7 inbound links and leave the other 49 idle.
+would funnel every band through the root's 7 inbound links and leave the other 49 idle.  The bands cross the
+links as RGB24 (`channels=3`): the alpha byte is the constant 255 in the reference (main.js:198), so it is not
+shipped; the de-interleave pass on the receiving rank restores it.
 
 Used by bench.py (GPU, backend "nccl") and by tests/test_shard_gloo.py (CPU, backend "gloo",
 world_size 2 and 3) — the same code path, only the band producer differs.
@@ -25,6 +27,11 @@ class TilePlan:
     h: int
     tile_rows: int
     world: int
+    channels: int = 4          # bytes per pixel of a band: 4 = RGBA8, 3 = RGB24 (RT_FLAG_RGB24; needs w % 4 == 0)
+
+    def __post_init__(self):
+        if self.channels not in (3, 4) or (self.channels == 3 and self.w % 4):
+            raise ValueError("TilePlan: channels must be 4, or 3 with a frame width that is a multiple of 4")
 
     @property
     def n_tiles(self):
@@ -40,7 +47,7 @@ class TilePlan:
 
     @property
     def band_bytes(self):
-        return self.band_rows * self.w * 4
+        return self.band_rows * self.w * self.channels
 
     def rt_tiles(self, rank):
         """(tile_rows, tile_first, tile_stride, n_tiles) for rt_render_tiles_device on `rank`."""
@@ -59,7 +66,7 @@ class TilePlan:
 
 
 def gather_bands(band, gathered, dst=0, async_op=False):
-    """One gather of every rank's band ([band_rows, w, 4] uint8) into `gathered` ([world, band_rows, w, 4],
+    """One gather of every rank's band ([band_rows, w, channels] uint8) into `gathered` ([world, band_rows, w, channels],
     rank `dst` only; None elsewhere).  Returns the work handle when async_op."""
     import torch.distributed as dist
     recv = list(gathered.unbind(0)) if dist.get_rank() == dst else None
@@ -68,22 +75,27 @@ def gather_bands(band, gathered, dst=0, async_op=False):
 
 def exchange_bands(send, recv, async_op=False):
     """One all-to-all over a batch of `world` frames: send[f] is this rank's band of frame f (shape
-    [world, band_rows, w, 4]); afterwards recv[g] is rank g's band of frame `rank` — the layout
+    [world, band_rows, w, channels]); afterwards recv[g] is rank g's band of frame `rank` — the layout
     deinterleave() expects."""
     import torch.distributed as dist
     return dist.all_to_all_single(recv.view(-1), send.view(-1), async_op=async_op)
 
 
 def deinterleave(plan, gathered, frame, lib=None, device_index=0, stream=0):
-    """gathered [world, band_rows, w, 4] -> frame [h, w, 4] in row order.
-    GPU tensors: the library's HBM->HBM kernel (rt_deinterleave_device) on `stream`.
+    """gathered [world, band_rows, w, channels] -> frame [h, w, 4] (RGBA8, alpha 255) in row order.
+    GPU tensors: the library's HBM->HBM kernel (rt_deinterleave[_rgb24]_device) on `stream`.
     CPU tensors (tests): the same permutation expressed with torch views."""
     if gathered.is_cuda:
-        rc = lib.rt_deinterleave_device(device_index, gathered.data_ptr(), frame.data_ptr(), plan.w, plan.h, plan.tile_rows, plan.world,
-                                        plan.band_bytes, stream)
+        fn = lib.rt_deinterleave_device if plan.channels == 4 else lib.rt_deinterleave_rgb24_device
+        rc = fn(device_index, gathered.data_ptr(), frame.data_ptr(), plan.w, plan.h, plan.tile_rows, plan.world, plan.band_bytes, stream)
         if rc != 0:
             raise RuntimeError("rt_deinterleave_device: " + lib.rt_last_error().decode())
         return frame
-    v = gathered.view(plan.world, plan.tiles_per_rank, plan.tile_rows, plan.w, 4).permute(1, 0, 2, 3, 4)
-    frame.copy_(v.reshape(-1, plan.w, 4)[:plan.h])
+    v = gathered.view(plan.world, plan.tiles_per_rank, plan.tile_rows, plan.w, plan.channels).permute(1, 0, 2, 3, 4)
+    rows = v.reshape(-1, plan.w, plan.channels)[:plan.h]
+    if plan.channels == 4:
+        frame.copy_(rows)
+    else:
+        frame[..., :3] = rows
+        frame[..., 3] = 255
     return frame

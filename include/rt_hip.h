@@ -126,7 +126,11 @@ typedef struct rt_stats {
 enum {
   RT_FLAG_NONE = 0,
   RT_FLAG_COUNT = 1,        /* run the counting variant and fill rays/shadow_rays/sphere_tests */
-  RT_FLAG_STRICT_FP = 2     /* no FMA contraction: operation-for-operation with the JS expression trees */
+  RT_FLAG_STRICT_FP = 2,    /* no FMA contraction: operation-for-operation with the JS expression trees */
+  RT_FLAG_RGB24 = 4         /* device entry points only: store 3 bytes per pixel (R,G,B, rows packed, w*3 bytes each)
+                             * instead of RGBA8.  The alpha byte is the constant 255 in the reference (main.js:198),
+                             * so a band that is about to cross an xGMI link does not carry it; the receiving side
+                             * restores it with rt_deinterleave_rgb24_device.  Needs w % 4 == 0. */
 };
 
 typedef struct rt_scene_dev rt_scene_dev; /* opaque: a scene resident in one GPU's HBM */
@@ -187,6 +191,12 @@ int rt_copy_to_host(int device, void *dst_host, const void *src_device, size_t b
 int rt_deinterleave_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h,
                            uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_bytes,
                            void *hip_stream);
+
+/* The same for bands rendered with RT_FLAG_RGB24: src rows are w*3 bytes, dst is the RGBA8 frame
+ * (ImageData.data layout) with the alpha byte set to 255.  Needs w % 4 == 0. */
+int rt_deinterleave_rgb24_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h,
+                                 uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_bytes,
+                                 void *hip_stream);
 
 #ifdef __cplusplus
 }

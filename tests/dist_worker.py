@@ -44,17 +44,19 @@ def main():
         print("DIST_RESULT world=%d identical=%d" % (world, ok), flush=True)
     # ---- throughput form: a batch of `world` frames, one all-to-all, every rank reassembles one frame.
     # The frames differ (frame f = the scene at depth 1+f) so that a mix-up of frames cannot go unnoticed.
+    # The bands travel as RGB24 (what bench.py does over RCCL); deinterleave() restores the alpha byte.
+    plan = shard.TilePlan(w, h, tile_rows, world, channels=3)
     scene_d = rt_host.load_scene(scene)
     blobs = []
     for f in range(world):
         sc = dict(scene_d)
         sc["segs"] = 1 + (f % 3)
         blobs.append(rt_host.flatten_scene(sc))
-    send = torch.zeros((world, plan.band_rows, w, 4), dtype=torch.uint8)
+    send = torch.zeros((world, plan.band_rows, w, 3), dtype=torch.uint8)
     for f in range(world):
         if rows:
             data = np.frombuffer(ou.c_oracle_rows(blobs[f], w, h, rows), dtype=np.uint8).reshape(len(rows), w, 4)
-            send[f, :len(rows)] = torch.from_numpy(data.copy())
+            send[f, :len(rows)] = torch.from_numpy(data[..., :3].copy())
     recv = torch.empty_like(send)
     shard.exchange_bands(send, recv, async_op=True).wait()
     mine = torch.empty((h, w, 4), dtype=torch.uint8)

@@ -313,6 +313,123 @@ def test_deinterleave_kernel_wide_and_ragged(lib):
         assert np.array_equal(np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4), want), (w, h, tile_rows, G)
 
 
+def gpu_tiles_rgb24(lib, scene, w, h, tiles, flags=0, n_frames=1):
+    """The same tiles with RT_FLAG_RGB24: n_frames bands of w*3 bytes per row."""
+    r = rt_host.Renderer(scene, 0, lib)
+    t = rt_host.RtTiles(*tiles)
+    band = t.n_tiles * t.tile_rows * w * 3
+    d = lib.rt_alloc_device(0, band * n_frames + 64)
+    assert d, lib.rt_last_error()
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemset(C.c_void_p(d), 0xA5, C.c_size_t(band * n_frames + 64)) == 0
+        r.render_batch(w, h, d, t, n_frames, band, flags=flags | rt_host.RT_FLAG_RGB24, want_stats=True)
+        host = C.create_string_buffer(band * n_frames + 64)
+        assert lib.rt_copy_to_host(0, host, d, band * n_frames + 64) == 0, lib.rt_last_error()
+        assert host.raw[band * n_frames:] == b"\xa5" * 64            # nothing written past the last band
+        return host.raw[:band * n_frames]
+    finally:
+        lib.rt_free_device(0, d)
+        r.close()
+
+
+@pytest.mark.parametrize("scene,w,h,tiles", [
+    ("h8", 200, 150, (150, 0, 1, 1)),          # right-edge group of 8 pixels (200 = 6*32 + 8)
+    ("h8", 100, 37, (8, 1, 2, 2)),             # right-edge group of 4 pixels, interleaved tiles, rows past the frame end
+    ("h8", 4, 9, (9, 0, 1, 1)),                # a frame narrower than one group
+    ("default14", 132, 40, (16, 0, 1, 3)),     # general (refraction) kernel
+    ("lcg64", 96, 64, (16, 1, 2, 2)),          # supersampled: the box filter feeds the packed store
+    ("lcg64_ss1", 64, 48, (48, 0, 1, 1))])     # shadow-grid variant
+@pytest.mark.parametrize("flags", [FAST, STRICT], ids=["fma", "strict"])
+def test_rgb24_store_equals_rgba_without_alpha(lib, scene, w, h, tiles, flags):
+    """RT_FLAG_RGB24 (the form in which bands cross xGMI): the packed 3-byte store must hold exactly the R,G,B of
+    the RGBA8 store, for every row the RGBA8 launch writes, and must not touch the rows it does not."""
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    t = rt_host.RtTiles(*tiles)
+    rgba = np.frombuffer(gpu_tiles(lib, blob, w, h, tiles, flags), dtype=np.uint8).reshape(-1, w, 4)
+    n_frames = 2
+    rgb = np.frombuffer(gpu_tiles_rgb24(lib, blob, w, h, tiles, flags, n_frames), dtype=np.uint8).reshape(n_frames, -1, w, 3)
+    valid = np.zeros(t.n_tiles * t.tile_rows, dtype=bool)
+    for i in range(t.n_tiles):
+        r0 = (t.tile_first + i * t.tile_stride) * t.tile_rows
+        valid[i * t.tile_rows:i * t.tile_rows + max(0, min(h, r0 + t.tile_rows) - r0)] = True
+    for f in range(n_frames):
+        assert np.array_equal(rgb[f][valid], rgba[valid][..., :3]), (scene, w, h, tiles, f)
+        assert (rgb[f][~valid] == 0xA5).all()                        # rows past the frame end stay untouched
+    assert (rgba[valid][..., 3] == 255).all()
+
+
+def test_rgb24_needs_width_multiple_of_4(lib):
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    r = rt_host.Renderer(blob, 0, lib)
+    d = lib.rt_alloc_device(0, 1 << 16)
+    try:
+        with pytest.raises(RuntimeError, match="multiple of 4"):
+            r.render_tiles(30, 8, d, rt_host.RtTiles(8, 0, 1, 1), flags=rt_host.RT_FLAG_RGB24)
+    finally:
+        lib.rt_free_device(0, d)
+        r.close()
+    out = lib.rt_alloc_pinned(64 * 64 * 4)
+    try:
+        st = rt_host.RtStats()
+        assert lib.rt_render(blob, len(blob), 64, 64, out, rt_host.RT_FLAG_RGB24, C.byref(st)) == -1
+    finally:
+        lib.rt_free_pinned(out)
+
+
+def test_deinterleave_rgb24_kernel(lib):
+    """rt_deinterleave_rgb24_device: RGB24 bands -> RGBA8 frame with alpha 255, against numpy."""
+    rng = np.random.default_rng(5)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    for w, h, tile_rows, G in [(64, 50, 16, 3), (36, 41, 8, 2), (3840, 64, 16, 4), (4, 5, 1, 4)]:
+        n_tiles = (h + tile_rows - 1) // tile_rows
+        per_rank = (n_tiles + G - 1) // G
+        band_rows = per_rank * tile_rows
+        src = rng.integers(0, 256, size=(G, band_rows, w, 3), dtype=np.uint8)
+        want = np.full((h, w, 4), 255, dtype=np.uint8)
+        want[..., :3] = src.reshape(G, per_rank, tile_rows, w, 3).transpose(1, 0, 2, 3, 4).reshape(-1, w, 3)[:h]
+        d_src = lib.rt_alloc_device(0, src.nbytes)
+        d_dst = lib.rt_alloc_device(0, w * h * 4)
+        try:
+            assert hip.hipMemcpy(C.c_void_p(d_src), src.ctypes.data_as(C.c_void_p), C.c_size_t(src.nbytes), 1) == 0
+            assert lib.rt_deinterleave_rgb24_device(0, d_src, d_dst, w, h, tile_rows, G, band_rows * w * 3, None) == 0, lib.rt_last_error()
+            host = C.create_string_buffer(w * h * 4)
+            assert lib.rt_copy_to_host(0, host, d_dst, w * h * 4) == 0
+        finally:
+            lib.rt_free_device(0, d_src)
+            lib.rt_free_device(0, d_dst)
+        assert np.array_equal(np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4), want), (w, h, tile_rows, G)
+    assert lib.rt_deinterleave_rgb24_device(0, 16, 16, 30, 8, 8, 2, 8 * 30 * 3, None) == -1
+
+
+def test_rgb24_bands_reassemble_the_frame(lib):
+    """The N>1 data path on one GPU: every rank's RGB24 band of interleaved 16-row tiles, de-interleaved with the alpha
+    restored, is the frame a single launch writes — at the headline size."""
+    import ctypes
+    import shard
+    hip = ctypes.CDLL("libamdhip64.so")
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    w, h, G = 3840, 2160, 4
+    plan = shard.TilePlan(w, h, 16, G, channels=3)
+    whole = gpu_frame(lib, blob, w, h)
+    d_bands = lib.rt_alloc_device(0, plan.band_bytes * G)
+    d_frame = lib.rt_alloc_device(0, w * h * 4)
+    r = rt_host.Renderer(blob, 0, lib)
+    try:
+        for g in range(G):
+            r.render_tiles(w, h, d_bands + g * plan.band_bytes, rt_host.RtTiles(*plan.rt_tiles(g)), flags=rt_host.RT_FLAG_RGB24, want_stats=True)
+        assert lib.rt_deinterleave_rgb24_device(0, d_bands, d_frame, w, h, 16, G, plan.band_bytes, None) == 0, lib.rt_last_error()
+        host = C.create_string_buffer(w * h * 4)
+        assert lib.rt_copy_to_host(0, host, d_frame, w * h * 4) == 0
+    finally:
+        r.close()
+        lib.rt_free_device(0, d_bands)
+        lib.rt_free_device(0, d_frame)
+    assert host.raw == whole
+
+
 @pytest.mark.parametrize("seed,n,lights", [
     (21, 16, [[0.0, 2.0, 0.0]]),                                           # light in the middle of the cluster: spheres all around it
     (22, 40, [[5.0, 10.0, 5.0], [-3.0, 0.6, 2.0]]),                        # a light near the floor, among the spheres

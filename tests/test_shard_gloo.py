@@ -29,6 +29,25 @@ def test_tile_plan_covers_every_row_once():
         assert plan.band_rows * world >= h
         for g in range(world):
             assert plan.rt_tiles(g) == (tr, g, world, plan.tiles_per_rank)
+        # RGB24 bands: same rows, three quarters of the bytes
+        p3 = shard.TilePlan(w, h, tr, world, channels=3)
+        assert p3.band_bytes * 4 == plan.band_bytes * 3 and p3.rows_of(0) == plan.rows_of(0)
+    with pytest.raises(ValueError):
+        shard.TilePlan(30, 8, 8, 2, channels=3)          # RGB24 needs w % 4 == 0
+
+
+def test_deinterleave_rgb24_on_cpu_restores_alpha():
+    import torch
+    plan = shard.TilePlan(8, 21, 4, 3, channels=3)
+    frame = torch.randint(0, 256, (plan.h, plan.w, 4), dtype=torch.uint8)
+    frame[..., 3] = 255
+    gathered = torch.zeros((plan.world, plan.band_rows, plan.w, 3), dtype=torch.uint8)
+    for g in range(plan.world):
+        for k, row in enumerate(plan.rows_of(g)):
+            gathered[g, k] = frame[row, :, :3]
+    out = torch.zeros_like(frame)
+    shard.deinterleave(plan, gathered, out)
+    assert torch.equal(out, frame)
 
 
 @pytest.mark.parametrize("world,scene,w,h,tile_rows", [(2, "h8", 64, 48, 8), (2, "cfg2", 40, 37, 16), (3, "default14", 32, 26, 8)])
