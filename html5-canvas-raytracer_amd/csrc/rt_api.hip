@@ -61,6 +61,11 @@ struct lib_state {
   void *rccl = nullptr;
   void *comms[16] = {nullptr};
   bool comms_ready = false;
+  // RT_EMULATE_DEVICES=N (test aid for 1-GPU boxes): rt_init reports N devices that all map to HIP device 0, and
+  // rt_render's gather becomes device-to-device copies instead of ncclGather (RCCL refuses two ranks on one GPU).
+  // Everything else of the multi-GPU frame - tile plan, per-device scenes and streams, RGB24 bands, de-interleave -
+  // runs as on a real node.
+  bool emulated = false;
 } G;
 
 int ensure_device(int d) {
@@ -104,10 +109,13 @@ extern "C" int rt_init(int max_devices) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
     return fail(RT_ERR_DEVICE, "no HIP device visible (%s); this library has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+  const char *emu = getenv("RT_EMULATE_DEVICES");
+  G.emulated = emu && atoi(emu) > 1;
+  if (G.emulated) n = atoi(emu);
   if (max_devices > 0 && n > max_devices) n = max_devices;
   if (n > 16) n = 16;
   G.dev.resize(n);
-  for (int i = 0; i < n; i++) G.dev[i].hip_id = i;
+  for (int i = 0; i < n; i++) G.dev[i].hip_id = G.emulated ? 0 : i;
   G.inited = true;
   return RT_OK;
 }
@@ -748,11 +756,14 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
   } else {
     // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
     //      GPU stores its tiles contiguously, ONE RCCL gather to GPU 0 over xGMI, one de-interleave pass ----
-    if ((rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
+    if (!G.emulated && (rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
     const uint32_t tile_rows = (h >= (uint32_t)ndev * 64u) ? 16u : RT_TILE_H;
     const uint32_t n_tiles_total = (h + tile_rows - 1) / tile_rows;
     const uint32_t tiles_per_rank = (n_tiles_total + ndev - 1) / ndev;
-    const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * 4u;
+    // bands cross xGMI as RGB24 when the width allows it (the alpha byte is the constant 255, main.js:198; the
+    // de-interleave restores it); tile_rows >= 8, so a band is a multiple of 96 bytes and d_final stays 16-byte aligned
+    const bool rgb24 = (w & 3u) == 0;
+    const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * (rgb24 ? 3u : 4u);
     std::vector<rt_scene_dev *> scenes(ndev, nullptr);
     rc = RT_OK;
     for (int g = 0; g < ndev && !rc; g++) {
@@ -776,10 +787,16 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
       if ((rc = ensure_device(g))) break;
       (void)hipEventCreate(&ev0[g]); (void)hipEventCreate(&ev1[g]);
       (void)hipEventRecord(ev0[g], G.dev[g].stream);
-      rc = rt_render_tiles_device(scenes[g], w, h, &t, G.dev[g].d_frame, nullptr, flags & ~RT_FLAG_COUNT, nullptr);
+      rc = rt_render_tiles_device(scenes[g], w, h, &t, G.dev[g].d_frame, nullptr, (flags & ~RT_FLAG_COUNT) | (rgb24 ? RT_FLAG_RGB24 : 0u), nullptr);
       (void)hipEventRecord(ev1[g], G.dev[g].stream);
     }
-    if (!rc) {
+    if (!rc && G.emulated) {                      // one physical GPU: the gather is a set of device-to-device copies
+      for (int g = 0; g < ndev; g++) {
+        hipError_t e = hipMemcpyAsync((uint8_t *)G.dev[0].d_gather + band_bytes * g, G.dev[g].d_frame, band_bytes, hipMemcpyDeviceToDevice, G.dev[g].stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(G.dev[g].stream);
+        if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "emulated gather: %s", hipGetErrorString(e));
+      }
+    } else if (!rc) {
       NCCL.group_start();
       for (int g = 0; g < ndev; g++) {
         (void)hipSetDevice(G.dev[g].hip_id);
@@ -791,7 +808,7 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
     if (!rc) {
       device_state &R = G.dev[0];
       uint8_t *d_final = (uint8_t *)R.d_gather + band_bytes * ndev;
-      rc = rt_deinterleave_device(0, R.d_gather, d_final, w, h, tile_rows, (uint32_t)ndev, band_bytes, nullptr);
+      rc = (rgb24 ? rt_deinterleave_rgb24_device : rt_deinterleave_device)(0, R.d_gather, d_final, w, h, tile_rows, (uint32_t)ndev, band_bytes, nullptr);
       if (!rc) {
         (void)hipSetDevice(R.hip_id);
         hipError_t e = hipMemcpyAsync(out_rgba, d_final, frame_bytes, hipMemcpyDeviceToHost, R.stream);

@@ -360,6 +360,30 @@ def test_rgb24_store_equals_rgba_without_alpha(lib, scene, w, h, tiles, flags):
     assert (rgba[valid][..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("devices", [2, 3, 8])
+def test_rt_render_multi_device_plan_on_emulated_devices(lib, devices):
+    """rt_render's multi-GPU frame (interleaved tiles per device -> gather to device 0 -> de-interleave -> copy-out) with
+    RT_EMULATE_DEVICES: N logical devices on the one physical GPU, the gather done by device-to-device copies because
+    RCCL refuses two ranks on one GPU.  Everything but the ncclGather call itself is the code a real node runs.  Cases:
+    16-row tiles + RGB24 bands (headline size), 8-row tiles, a width that forces RGBA8 bands, the general kernel, and a
+    frame too short to shard."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    cases = [("h8", 3840, 2160), ("h8", 200, 150), ("h8", 203, 97), ("default14", 132, 80), ("cfg1", 64, 9)]
+    env = dict(os.environ, RT_EMULATE_DEVICES=str(devices))
+    cmd = [sys.executable, os.path.join(ou.ROOT, "tests", "emulated_devices_check.py")] + ["%s:%d:%d" % c for c in cases]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == len(cases)
+    for (scene, w, h), got in zip(cases, lines):
+        assert got[:4] == [scene, str(w), str(h), str(devices)]
+        want = hashlib.sha256(gpu_frame(lib, rt_host.flatten_scene(rt_host.load_scene(scene)), w, h)).hexdigest()
+        assert got[4] == want, (scene, w, h, devices)
+
+
 def test_rgb24_needs_width_multiple_of_4(lib):
     blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
     r = rt_host.Renderer(blob, 0, lib)
