@@ -492,6 +492,25 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
                 }                                                                             \
               }                                                                               \
             }
+// The scans the product and strict kernels run (everything but the counting variant): no per-lane `break`.  A lane that
+// is already blocked (li == 0) keeps testing, and whatever it hits leaves li at 0 (0 / albedo, or 0), exactly where the
+// reference's `break` (main.js:301) left it.  The loop is then wave-uniform: the exec-mask bookkeeping of a divergent loop
+// exit - about 10 scalar instructions per iteration, for every wave - is gone (measured: +4.6 % on the headline).
+#define RT_SHADOW_U(J, G)                                                                     \
+            {                                                                               \
+              RT_SDISC(G, tc_, disc_)                                                       \
+              if (((int)(J) != hi) && !(disc_ < 0.0)) {                                     \
+                RT_PIN();                                                                   \
+                const double thc_ = rt_sqrt_nn(disc_);                                      \
+                RT_SROOTS(tc_, thc_, t0_, t1_)                                              \
+                const double t_ = (t0_ < eps) ? t1_ : t0_;                                  \
+                if ((t_ < llen) && !(t_ < eps) && li != 0.0) {                              \
+                  RT_PIN();                                                                 \
+                  const double oa4_ = objs[J].albedo[4];                                    \
+                  li = (oa4_ != 0.0) ? rt_div(li, oa4_) : 0.0;                              \
+                }                                                                           \
+              }                                                                             \
+            }
 #ifdef RT_ABLATE_SHADOW
             const uint32_t NS = 0;
 #else
@@ -519,7 +538,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
               const unsigned long long __attribute__((address_space(4))) *cells =
                   (const unsigned long long __attribute__((address_space(4))) *)((const double __attribute__((address_space(4))) *)L.shadow_grid + 16u * NL) +
                   (size_t)k * (RT_SGRID * RT_SGRID + 1u) * words;
-              for (uint32_t wd = 0; wd < words && !blocked; wd++) {
+              for (uint32_t wd = 0; wd < words; wd++) {
                 unsigned long long cand = 0ull, todo = __ballot(true);
                 while (todo) {
                   const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)__builtin_ctzll(todo));
@@ -530,12 +549,21 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
                   const uint32_t j = (wd << 6) + (uint32_t)__builtin_ctzll(cand);
                   cand &= cand - 1ull;
                   const rt_geom g0 = RT_LOAD(gl, j);
-                  RT_SHADOW(j, g0)
-                  if (blocked) break;
+                  RT_SHADOW_U(j, g0)                                                          // the grid variant never counts
                 }
               }
             } else
 #endif
+            if (!COUNT) {
+              if (li != 0.0) {
+                uint32_t j = 0;
+                for (; j + 2 <= NS; j += 2) {
+                  const rt_geom g0 = RT_LOAD(gl, j), g1 = RT_LOAD(gl, j + 1);
+                  RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
+                }
+                if (j < NS) { const rt_geom g0 = RT_LOAD(gl, j); RT_SHADOW_U(j, g0) }
+              }
+            } else
             if (COUNT || li != 0.0) {                  // li == 0 on entry (an earlier light was blocked) cannot change
               uint32_t j = 0;
               for (; j + 2 <= NS; j += 2) {
@@ -546,6 +574,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
               if (j < NS && !blocked) { const rt_geom g0 = RT_LOAD(gl, j); RT_SHADOW(j, g0) }
             }
 #undef RT_SHADOW
+#undef RT_SHADOW_U
 #undef RT_SROOTS
 #undef RT_SDISC
             if (COUNT) cnt[2] += tests;
