@@ -106,6 +106,20 @@ def test_restatement_bit_exact_vs_live_reference(scene, w, h):
     assert a["sha256"] == b["sha256"]
 
 
+@needs_ref
+@needs_node
+@pytest.mark.reference
+def test_restatements_vs_live_reference_on_random_scenes(built):
+    """A slice of tests/soak_oracle_vs_reference.py (600 scenes by hand: profiles/r01_soak_oracle_vs_reference.json):
+    random scenes far from the fixtures - sphere counts, samplers, transparent occluders, lights inside spheres, arbitrary
+    cameras, fov, depth, supersampling - through the reference's own intersectWorld; the JS restatement must be
+    bit-identical, the C restatement within 1 LSB with no flipped pixel."""
+    import soak_oracle_vs_reference as sr
+    res = sr.run(10, 1000, verbose=False)
+    assert res["scenes"] == 10 and res["restate_mismatch"] == []
+    assert res["c_flipped_pixels"] == 0
+
+
 # ---------------------------------------------------------------- hashed stars sampler (kind 3)
 @needs_node
 def test_stars_sampler_js_and_c_restatements_agree(built, tmp_path):
