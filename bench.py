@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails
+    # (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept here so a bare launch works too.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import rt_host
