@@ -368,7 +368,8 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   {
     // shadow grids, in the loop order the product kernel uses (B when there is an enclosing sphere)
     const uint32_t n_loop = has_b ? NO - 1 : NO;
-    if (n_loop > RT_SGRID_MIN_LOOP && hd->n_lights > 0) {
+    static const uint32_t sgrid_min = getenv("RT_SGRID_MIN") ? (uint32_t)atoi(getenv("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;   // A/B switch
+    if (n_loop > sgrid_min && hd->n_lights > 0) {
       const std::vector<uint64_t> sg = build_shadow_grid(has_b ? objs_b.data() : pob_a, n_loop, hd->n_lights, s->lights);
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
       if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
