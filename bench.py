@@ -17,8 +17,11 @@ worth of pixels at every N (weak scaling), every frame is reassembled by a singl
 collective uses all N(N-1) directed xGMI links at once (a gather to one root would be bound by that
 root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels, three links' worth).  The bands
 cross the links as RGB24 — the alpha byte is the constant 255 (main.js:198) and is restored by the
-de-interleave — which takes a quarter off the link time that bounds N=2 and N=4.  The
-exchange of step k overlaps the render of step k+1 (two buffer slots).  The scene is resident in HBM
+de-interleave — which takes a quarter off the link time that bounds N=2 and N=4.  The bands of 4 consecutive
+steps (RT_BENCH_EXCHANGE_EVERY) travel in ONE all_to_all_single: issuing a c10d collective costs the host
+about as much time as a step's GPU work (57 us measured for a 1-rank group against a 0.12 ms kernel), so one
+collective per step would leave the job host-bound.  A group's exchange overlaps the renders of the next
+group (two buffer slots).  The scene is resident in HBM
 before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the HBM-store roofline the
@@ -126,7 +129,13 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)          # this rank's reassembled frame
+    # N>1: ONE exchange serves `every` consecutive steps (RT_BENCH_EXCHANGE_EVERY, default 4): a c10d collective costs
+    # ~60-150 us of host time to issue (measured: 57 us for a 1-rank all_to_all_single), about as much as a step's GPU
+    # work, so issuing one per step would make the job host-bound; per-GPU work per STEP stays one frame's worth of
+    # pixels at every N, the bands of `every` steps travel together (larger messages also use the links better).
+    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "4"))) if world > 1 else 1
+    frames = torch.empty((every, h, w, 4), dtype=torch.uint8, device=dev)   # the frames this rank reassembles (N=1: the frame)
+    frame = frames[0]
     # Opt-in (RT_BENCH_TWO_STREAMS=1, N=1): consecutive frames alternate between two HIP streams and two frame
     # buffers, so the tail of frame k overlaps the head of frame k+1 (+3 % measured).  Off by default so that
     # every launch of the timed region runs alone and rocprof's per-kernel average equals `kernel_ms`.
@@ -136,30 +145,42 @@ def main():
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
     if world > 1:
-        send = [torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        host_recv = torch.empty((world, plan.band_rows, w, channels), dtype=torch.uint8) if rehearse else None
-    pending = []      # (work, slot) of exchanges in flight; at most 2
-    # the wait for an exchange and the de-interleave that follows run on a SIDE stream, so the render stream
+        # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
+        send = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_recv = torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8) if rehearse else None
+    pending = []      # (work, slot, steps in it) of exchanges in flight; at most 2
+    group = {"slot": 0, "fill": 0}                                 # the exchange buffer being filled, and how many steps are in it
+    # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
     # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     slot_free = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
 
-    def render_step(slot):
+    def render_step(slot, j=0):
         if world == 1:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
-        else:   # this rank's tiles of all `world` frames of the batch, one launch
-            renderer.render_batch(w, h, send[slot].data_ptr(), my_tiles, world, plan.band_bytes, stream=stream, flags=batch_flags)
+        else:   # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
+            renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
 
-    def finish(slot_work):
-        work, slot = slot_work
+    def finish(item):
+        work, slot, count = item
         with torch.cuda.stream(side):
             work.wait()                                          # the side stream waits for the exchange
             if rehearse:
                 recv[slot].copy_(host_recv)
-            shard.deinterleave(plan, recv[slot], frame, lib=lib, device_index=dev_index, stream=side.cuda_stream)
+            for j in range(count):                               # one whole frame per step of the group ends up on this rank
+                shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
             slot_free[slot].record(side)
-        tstream.wait_event(slot_free[slot])                      # ordering only: that work is two steps old by the time it matters
+        tstream.wait_event(slot_free[slot])                      # ordering only: that work is two groups old by the time it matters
+
+    def launch_exchange():
+        slot = group["slot"]
+        if rehearse:
+            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
+        else:
+            work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
+        pending.append((work, slot, group["fill"]))              # overlaps with the renders of the next group
+        group["slot"], group["fill"] = slot ^ 1, 0
 
     def step(k):
         if world == 1:
@@ -168,17 +189,16 @@ def main():
             else:
                 render_step(0)
             return
-        slot = k & 1
-        if len(pending) == 2:                                    # the exchange that last used this slot
+        if group["fill"] == 0 and len(pending) == 2:             # about to refill a slot: the exchange that last used it
             finish(pending.pop(0))
-        render_step(slot)
-        if rehearse:
-            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
-        else:
-            work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
-        pending.append((work, slot))                             # overlaps with the next step's render
+        render_step(group["slot"], group["fill"])
+        group["fill"] += 1
+        if group["fill"] == every:
+            launch_exchange()
 
     def drain():
+        if world > 1 and group["fill"] > 0:                      # a partial group still travels (whole buffer; only its steps count)
+            launch_exchange()
         while pending:
             finish(pending.pop(0))
 
@@ -221,15 +241,19 @@ def main():
 
     # one more (untimed) step; EVERY rank checks the frame it reassembled against the rows the reference itself
     # rendered (tests/golden, fixtures - not the oracle), and the worst rank is reported
-    step(0)
+    frames.zero_()
+    torch.cuda.synchronize()
+    for k in range(every):                                         # one whole group, so every frame slot is rewritten
+        step(k)
     drain()
     torch.cuda.synchronize()
     import oracle_util as ou
     max_lsb = None
     for f in ou.manifest()["frames"]:
         if f["scene"] == args.scene and (f["w"], f["h"]) == (w, h) and f["rows"]:
-            got = frame[f["rows"]].cpu().numpy().reshape(-1)
-            max_lsb = ou.max_lsb(got, ou.golden_frame(f))[0]
+            for j in range(every):
+                got = frames[j][f["rows"]].cpu().numpy().reshape(-1)
+                max_lsb = max(max_lsb or 0, ou.max_lsb(got, ou.golden_frame(f))[0])
     if world > 1 and max_lsb is not None:
         t = torch.tensor([int(max_lsb)], dtype=torch.int64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,8 +280,9 @@ def main():
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
         else:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
-                   "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; exchange of step k overlaps render of step k+1"
-                   % (world, TILE_ROWS, world, "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8"))
+                   "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
+                   "collective, which overlaps the renders of the next %d steps"
+                   % (world, TILE_ROWS, world, "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
         out = {
             "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -278,7 +303,8 @@ def main():
         }
         if world > 1:
             out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
-                               "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels}
+                               "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
+                               "steps_per_collective": every}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.scene, w, h)

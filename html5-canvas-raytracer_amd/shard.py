@@ -74,24 +74,30 @@ def gather_bands(band, gathered, dst=0, async_op=False):
 
 
 def exchange_bands(send, recv, async_op=False):
-    """One all-to-all over a batch of `world` frames: send[f] is this rank's band of frame f (shape
-    [world, band_rows, w, channels]); afterwards recv[g] is rank g's band of frame `rank` — the layout
-    deinterleave() expects."""
+    """One all-to-all over a batch of frames: send[f] holds this rank's band(s) for rank f (shape
+    [world, band_rows, w, channels], or [world, B, band_rows, w, channels] when B steps share one exchange);
+    afterwards recv[g] holds rank g's band(s) of the frame(s) this rank owns - the layout deinterleave() expects
+    (recv[:, j] for the j-th frame)."""
     import torch.distributed as dist
     return dist.all_to_all_single(recv.view(-1), send.view(-1), async_op=async_op)
 
 
 def deinterleave(plan, gathered, frame, lib=None, device_index=0, stream=0):
     """gathered [world, band_rows, w, channels] -> frame [h, w, 4] (RGBA8, alpha 255) in row order.
+    `gathered` may be a view with any stride between ranks (e.g. buf[:, j] of a [world, B, band_rows, w, channels]
+    exchange buffer that holds B frames per rank); each rank's band itself must be contiguous.
     GPU tensors: the library's HBM->HBM kernel (rt_deinterleave[_rgb24]_device) on `stream`.
     CPU tensors (tests): the same permutation expressed with torch views."""
+    if tuple(gathered.shape) != (plan.world, plan.band_rows, plan.w, plan.channels) or not gathered[0].is_contiguous():
+        raise ValueError("deinterleave: expected [world, band_rows, w, channels] with contiguous bands")
     if gathered.is_cuda:
         fn = lib.rt_deinterleave_device if plan.channels == 4 else lib.rt_deinterleave_rgb24_device
-        rc = fn(device_index, gathered.data_ptr(), frame.data_ptr(), plan.w, plan.h, plan.tile_rows, plan.world, plan.band_bytes, stream)
+        rank_stride = gathered.stride(0) * gathered.element_size() if plan.world > 1 else plan.band_bytes
+        rc = fn(device_index, gathered.data_ptr(), frame.data_ptr(), plan.w, plan.h, plan.tile_rows, plan.world, rank_stride, stream)
         if rc != 0:
             raise RuntimeError("rt_deinterleave_device: " + lib.rt_last_error().decode())
         return frame
-    v = gathered.view(plan.world, plan.tiles_per_rank, plan.tile_rows, plan.w, plan.channels).permute(1, 0, 2, 3, 4)
+    v = gathered.reshape(plan.world, plan.tiles_per_rank, plan.tile_rows, plan.w, plan.channels).permute(1, 0, 2, 3, 4)
     rows = v.reshape(-1, plan.w, plan.channels)[:plan.h]
     if plan.channels == 4:
         frame.copy_(rows)
