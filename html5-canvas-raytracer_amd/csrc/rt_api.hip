@@ -89,6 +89,7 @@ struct rt_scene_dev {
   rt_geom *d_geom;               // geometry tables, two orderings: [A: plain, camera, lights][B: plain, camera, lights]
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
   uint64_t *d_shadow_grid;       // light grids for the product kernel's loop order, or NULL (few spheres)
+  uint64_t *d_bounce_table;      // bounce table for the same order, or NULL (few spheres, or depth < 2)
   uint8_t *d_lds_image;          // per ordering: [materials | 16 texture descriptors | cull rectangles], the LDS image
   size_t lds_image_bytes;        // of one ordering
   rt_scene_header hd;            // host copy
@@ -268,6 +269,96 @@ std::vector<uint64_t> build_shadow_grid(const rt_sphere *objs, uint32_t n_loop, 
 }
 }  // namespace
 
+// Bounce table (product kernel, scenes with many spheres).  A reflected or refracted ray starts on the sphere it
+// just hit, so its origin lies in that sphere's ball B(C_i, r_i); its direction d falls in one cell of a cube map with
+// RT_BGRID x RT_BGRID cells per face.  Entry (i, cell) is the bit set of the loop spheres j that SOME ray from a point of
+// B(C_i, r_i) with a direction of the cell can meet in front of its origin:
+//     the line through p in B(C_i, r_i) with direction d passes within r_j of C_j only if the line through C_i with
+//     direction d passes within R = r_i + r_j of C_j, i.e. only if the angle between d and D = C_j - C_i is at most
+//     asin(R / |D|) (or the spheres are within R of each other: every direction), and the sphere lies ahead only for that
+//     branch (not the one around -D); a cell is the cone around its centre direction with the half-angle of its farthest
+//     corner.
+// Everything is widened (1e-9 relative on R, 1e-6 rad on the cone) so that the kernel's own rounding - its hit point is
+// on the sphere only up to an ulp, its cell index comes from a 2^-24 reciprocal - cannot put a ray outside the set its
+// entry describes.  The table only prunes the candidates of the closest-hit search; the tests themselves are unchanged.
+// Layout: [n_objects][RT_BCELLS][words] uint64, bit j = loop sphere j (device order).
+namespace {
+std::vector<uint64_t> build_bounce_table(const rt_sphere *objs, uint32_t n_objects, uint32_t n_loop) {
+  const uint32_t K = RT_BGRID, cells = RT_BCELLS, words = (n_loop + 63u) / 64u;
+  std::vector<uint64_t> tab((size_t)n_objects * cells * words, 0ull);
+  // cell cones: centre direction, cos/sin of the half-angle (the kernel's mapping: face = 2*major axis + (negative), u/v =
+  // the other two axes in x,y,z order, a = u/|major|, b = v/|major| in [-1,1], cell = floor((a+1)K/2))
+  std::vector<double> cdir(3u * cells), ccos(cells), csin(cells);
+  for (uint32_t f = 0; f < 6; f++) {
+    const int m = (int)(f >> 1), ua = (m == 0) ? 1 : 0, va = (m == 2) ? 1 : 2;
+    const double sgn = (f & 1u) ? -1.0 : 1.0;
+    for (uint32_t ib = 0; ib < K; ib++) for (uint32_t ia = 0; ia < K; ia++) {
+      const uint32_t c = f * K * K + ib * K + ia;
+      const double a0 = -1.0 + 2.0 * ia / K, a1 = -1.0 + 2.0 * (ia + 1) / K, b0 = -1.0 + 2.0 * ib / K, b1 = -1.0 + 2.0 * (ib + 1) / K;
+      double ctr[3] = {0, 0, 0};
+      ctr[m] = sgn; ctr[ua] = 0.5 * (a0 + a1); ctr[va] = 0.5 * (b0 + b1);
+      const double cl = sqrt(ctr[0] * ctr[0] + ctr[1] * ctr[1] + ctr[2] * ctr[2]);
+      for (int k = 0; k < 3; k++) ctr[k] /= cl;
+      double worst = 1.0;                                   // smallest cosine between the centre and a corner
+      for (int q = 0; q < 4; q++) {
+        double v[3] = {0, 0, 0};
+        v[m] = sgn; v[ua] = (q & 1) ? a1 : a0; v[va] = (q & 2) ? b1 : b0;
+        const double vl = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        worst = fmin(worst, (v[0] * ctr[0] + v[1] * ctr[1] + v[2] * ctr[2]) / vl);
+      }
+      const double half = acos(fmax(-1.0, fmin(1.0, worst))) + 1e-6;
+      for (int k = 0; k < 3; k++) cdir[3u * c + k] = ctr[k];
+      ccos[c] = cos(half); csin[c] = sin(half);
+    }
+  }
+  for (uint32_t i = 0; i < n_objects; i++) {
+    const double ri = sqrt(objs[i].r2);
+    uint64_t *row = tab.data() + (size_t)i * cells * words;
+    for (uint32_t j = 0; j < n_loop; j++) {
+      const double D[3] = {objs[j].origin[0] - objs[i].origin[0], objs[j].origin[1] - objs[i].origin[1], objs[j].origin[2] - objs[i].origin[2]};
+      const double Ld = sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+      const double R = (ri + sqrt(objs[j].r2)) * (1.0 + 1e-9);
+      const uint64_t bit = 1ull << (j & 63u);
+      const bool everywhere = !(R < Ld * (1.0 - 1e-9)) || !std::isfinite(R) || !std::isfinite(Ld);   // overlapping / containing / degenerate: all cells
+      const double sa = everywhere ? 1.0 : R / Ld, ca = everywhere ? 0.0 : sqrt(fmax(0.0, 1.0 - sa * sa));
+      for (uint32_t c = 0; c < cells; c++) {
+        bool cand = everywhere;
+        if (!cand) {
+          // angle(centre, D) <= alpha + half  <=>  cos(angle) >= cos(alpha + half) when alpha + half < pi
+          const double cosang = (cdir[3u * c] * D[0] + cdir[3u * c + 1] * D[1] + cdir[3u * c + 2] * D[2]) / Ld;
+          const double cos_sum = ca * ccos[c] - sa * csin[c], sin_sum = sa * ccos[c] + ca * csin[c];   // alpha, half in (0, pi/2): sum < pi
+          cand = (sin_sum <= 0.0) || (cosang >= cos_sum - 1e-12);
+        }
+        if (cand) row[(size_t)c * words + (j >> 6)] |= bit;
+      }
+    }
+  }
+  return tab;
+}
+}  // namespace
+
+// Host-logic probe for tests: the bounce table's answer for one ray, with the kernel's own direction -> cell mapping
+// (an exact division where the kernel uses a 2^-24 reciprocal: the cells overlap by 1e-6 rad for that).
+extern "C" int rt_scene_bounce_candidates(const void *blob, size_t bytes, uint32_t from, const double dir[3], uint64_t *out_words) {
+  int rc = rt_scene_validate(blob, bytes);
+  if (rc) return rc;
+  const rt_scene_header *hd = (const rt_scene_header *)blob;
+  if (!dir || !out_words || from >= hd->n_objects) return fail(RT_ERR_INVALID, "bad bounce probe arguments");
+  const rt_sphere *ob = (const rt_sphere *)((const uint8_t *)blob + hd->objects_offset);
+  const uint32_t n = hd->n_objects, words = (n + 63u) / 64u;
+  const std::vector<uint64_t> tab = build_bounce_table(ob, n, n);
+  const double ax = fabs(dir[0]), ay = fabs(dir[1]), az = fabs(dir[2]);
+  const bool bx = (ax >= ay) && (ax >= az), by = !bx && (ay >= az);
+  const double dm = bx ? dir[0] : (by ? dir[1] : dir[2]);
+  const double du = bx ? dir[1] : dir[0], dv = (bx || by) ? dir[2] : dir[1];
+  const double sc = (0.5 * RT_BGRID) / fabs(dm);
+  const double fu = fmin(fmax(du * sc + 0.5 * RT_BGRID, 0.0), (double)(RT_BGRID - 1u)), fv = fmin(fmax(dv * sc + 0.5 * RT_BGRID, 0.0), (double)(RT_BGRID - 1u));
+  const uint32_t face = (bx ? 0u : (by ? 2u : 4u)) + ((dm < 0.0) ? 1u : 0u);
+  const uint32_t cell = face * (RT_BGRID * RT_BGRID) + (uint32_t)fv * RT_BGRID + (uint32_t)fu;
+  memcpy(out_words, tab.data() + ((size_t)from * RT_BCELLS + cell) * words, words * sizeof(uint64_t));
+  return RT_OK;
+}
+
 // Host-logic probe for tests: the cull rectangle of every sphere, scene order, 4 doubles each.
 extern "C" int rt_scene_cull_rects(const void *blob, size_t bytes, double *out) {
   int rc = rt_scene_validate(blob, bytes);
@@ -291,7 +382,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if ((rc = ensure_device(device))) return rc;
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
-  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr; s->d_shadow_grid = nullptr;
+  s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr; s->d_shadow_grid = nullptr; s->d_bounce_table = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -374,6 +465,12 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
       if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     }
+    static const uint32_t btable_min = getenv("RT_BTABLE_MIN") ? (uint32_t)atoi(getenv("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;   // A/B switch
+    if (n_loop > btable_min && hd->segs > 1) {      // rays bounce at all only from depth 2 on
+      const std::vector<uint64_t> bt = build_bounce_table(has_b ? objs_b.data() : pob_a, NO, n_loop);
+      if (e == hipSuccess) e = hipMalloc((void **)&s->d_bounce_table, bt.size() * sizeof(uint64_t));
+      if (e == hipSuccess) e = hipMemcpy(s->d_bounce_table, bt.data(), bt.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess && has_b) e = hipMalloc((void **)&s->d_objects_b, objs_b.size() * sizeof(rt_sphere));
   if (e == hipSuccess && has_b) e = hipMemcpy(s->d_objects_b, objs_b.data(), objs_b.size() * sizeof(rt_sphere), hipMemcpyHostToDevice);
@@ -386,6 +483,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     if (s->d_objects_b) (void)hipFree(s->d_objects_b);
     if (s->d_lds_image) (void)hipFree(s->d_lds_image);
     if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
+    if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
     delete s;
     return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
   }
@@ -402,6 +500,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (s->d_objects_b) (void)hipFree(s->d_objects_b);
   if (s->d_lds_image) (void)hipFree(s->d_lds_image);
   if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
+  if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
   delete s;
 }
 
@@ -445,6 +544,8 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   // the grids are built for the product kernel's order: B if the scene has an enclosing sphere, else the scene's own
   static const bool no_grid = getenv("RT_NO_SHADOW_GRID") != nullptr;     // A/B switch for the profiles/ scripts
   L.shadow_grid = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && !no_grid) ? s->d_shadow_grid : nullptr;
+  static const bool no_bounce = getenv("RT_NO_BOUNCE_TABLE") != nullptr;  // A/B switch
+  L.bounce_table = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && !no_bounce) ? s->d_bounce_table : nullptr;
   L.geom_light = gt + 3 * (size_t)hd.n_objects;
   L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
   L.enclosing = order_b ? hd.n_objects - 1 : ~0u;

@@ -245,7 +245,7 @@ template <> struct frame<false> { double amb[3], ds[3], a3; };
 template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3]; int has_f, phase; };
 // A parked two-child node of the product general kernel: its own terms, its refraction ray, and the map F that
 // was accumulated above it (S, O, LO, HI), to be restored when its reflection subtree has been evaluated.
-struct park { double amb[3], ds[3], a3, a4, h[3], f[3], S, O[3], LO[3], HI[3]; uint32_t path, segs_left; int level, map_valid; };
+struct park { double amb[3], ds[3], a3, a4, h[3], f[3], S, O[3], LO[3], HI[3]; uint32_t path, segs_left; int level, map_valid, hcode; };
 
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
@@ -343,13 +343,61 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // ---------------- evaluate one intersectWorld node (segs_left > 0 here) ----------------
       if (COUNT) cnt[0]++;
       if (!searched) {                              // reflection / refraction rays: any origin, generic form
-        ht = RT_INF; hcode = -1;
-        uint32_t i = 0;
-        for (; i + 2 <= NLOOP; i += 2) {
-          const rt_geom g0 = RT_LOAD(geom, i), g1 = RT_LOAD(geom, i + 1);
-          RT_GENERIC(i, g0) RT_GENERIC(i + 1, g1)
+        bool scanned = false;
+#if !RT_STRICT
+        if constexpr (GRID) {
+          if (L.bounce_table != nullptr) {
+            // Many spheres: a bounced ray starts ON the sphere it just hit (`hcode` still names it) and its direction
+            // falls in one cell of a cube map.  The host stored, per (sphere, cell), the bit set of the spheres that
+            // ANY ray leaving that sphere's ball in ANY direction of that cell can meet (conservative: angle between
+            // the cell and the line of centres against asin((r_i + r_j) / distance), rt_api.hip build_bounce_table).
+            // The wave tests the UNION over its active lanes, walked like the shadow grid's cells (readlane + ballot,
+            // correct under divergence), in index order, so the strict-< tie-break of the full scan is kept.
+            const uint32_t from = (uint32_t)(hcode >> 1);
+            const double ax = __builtin_fabs(d.x), ay = __builtin_fabs(d.y), az = __builtin_fabs(d.z);
+            const bool bx = (ax >= ay) && (ax >= az), by = !bx && (ay >= az);
+            const double dm = bx ? d.x : (by ? d.y : d.z);
+            const double du = bx ? d.y : d.x, dv = (bx || by) ? d.z : d.y;
+            const double sc = (0.5 * RT_BGRID) * __builtin_amdgcn_rcp(__builtin_fabs(dm));   // 2^-24 is plenty: the host's cells overlap by 1e-6
+            const double fu = __builtin_fmin(__builtin_fmax(__builtin_fma(du, sc, 0.5 * RT_BGRID), 0.0), (double)(RT_BGRID - 1u));
+            const double fv = __builtin_fmin(__builtin_fmax(__builtin_fma(dv, sc, 0.5 * RT_BGRID), 0.0), (double)(RT_BGRID - 1u));
+            const uint32_t face = (bx ? 0u : (by ? 2u : 4u)) + ((dm < 0.0) ? 1u : 0u);
+            const uint32_t key = from * RT_BCELLS + face * (RT_BGRID * RT_BGRID) + (uint32_t)fv * RT_BGRID + (uint32_t)fu;
+            const uint32_t words = (NLOOP + 63u) >> 6;
+            const unsigned long long __attribute__((address_space(4))) *tab = (const unsigned long long __attribute__((address_space(4))) *)L.bounce_table;
+            ht = RT_INF; hcode = -1;
+            for (uint32_t wd = 0; wd < words; wd++) {
+              unsigned long long cand = 0ull, todo = __ballot(true);
+              uint32_t distinct = 0;
+              while (todo) {
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
+                cand |= tab[(size_t)k0 * words + wd];
+                todo &= ~__ballot(key == k0);
+                if (++distinct == 16u && todo) {           // a wave whose rays fan out over many cells: scan everything
+                  cand = (wd + 1u == words && (NLOOP & 63u)) ? ((1ull << (NLOOP & 63u)) - 1ull) : ~0ull;
+                  break;
+                }
+              }
+              while (cand) {
+                const uint32_t j = (wd << 6) + (uint32_t)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                const rt_geom g0 = RT_LOAD(geom, j);
+                RT_GENERIC(j, g0)
+              }
+            }
+            scanned = true;
+          }
         }
-        if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
+#endif
+        if (!scanned) {
+          ht = RT_INF; hcode = -1;
+          uint32_t i = 0;
+          for (; i + 2 <= NLOOP; i += 2) {
+            const rt_geom g0 = RT_LOAD(geom, i), g1 = RT_LOAD(geom, i + 1);
+            RT_GENERIC(i, g0) RT_GENERIC(i + 1, g1)
+          }
+          if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
+        }
       }
       searched = false;
       // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) is
@@ -517,7 +565,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             const uint32_t NS = NLOOP;
 #endif
 #if !RT_STRICT
-            if (GRID && li != 0.0) {
+            if (GRID && L.shadow_grid != nullptr && li != 0.0) {
               // Many spheres: cull the scan with the light's grid.  The host cut light k's view of the scene
               // (projective coordinates x'/z', y'/z' in a frame looking from the light at the scene) into
               // RT_SGRID x RT_SGRID cells and stored, per cell, the bit set of spheres whose conservative rectangle
@@ -665,7 +713,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #pragma unroll
             for (int c = 0; c < 3; c++) { pk.amb[c] = A[c]; pk.ds[c] = D[c]; }
             pk.a3 = a3; pk.a4 = a4; pk.h[0] = h.x; pk.h[1] = h.y; pk.h[2] = h.z; pk.f[0] = f.x; pk.f[1] = f.y; pk.f[2] = f.z;
-            pk.path = tree_path; pk.segs_left = segs_left; pk.level = level; pk.map_valid = map_valid;
+            pk.path = tree_path; pk.segs_left = segs_left; pk.level = level; pk.map_valid = map_valid; pk.hcode = hcode;
             if (map_valid) {
               pk.S = acc[0];
 #pragma unroll
@@ -750,6 +798,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             map_valid = true;
             p = mk(pk.h[0], pk.h[1], pk.h[2]); d = mk(pk.f[0], pk.f[1], pk.f[2]);
             tree_path = 2u * pk.path + 1u; segs_left = pk.segs_left - 1u; level = pk.level + 1;
+            hcode = pk.hcode;                          // the refraction ray starts on the parked node's sphere (bounce table)
             resumed = true;
           }
         }
@@ -906,7 +955,7 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
   const dim3 grid(L->tiles_x, L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
   // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
-  const bool grid_variant = !RT_STRICT && !count && L->shadow_grid != nullptr;
+  const bool grid_variant = !RT_STRICT && !count && (L->shadow_grid != nullptr || L->bounce_table != nullptr);
   if (grid_variant) {
 #if !RT_STRICT
     if (!refract) { if (!ss2) RT_CASE(false, false, false, true); else RT_CASE(false, false, true, true); }

@@ -150,6 +150,11 @@ int rt_scene_validate(const void *scene_blob, size_t blob_bytes);
  * line meets the sphere (X = x - w/2 + 0.5, Y = h/2 - y - 0.5, D = (w/2)/tan(fov/2); +-inf = unbounded). */
 int rt_scene_cull_rects(const void *scene_blob, size_t blob_bytes, double *out_4n);
 
+/* Host-logic probe (no GPU): the candidate set the product kernel's bounce table gives a reflected / refracted ray
+ * that starts on sphere `from` (scene order) with direction `dir`: bit j of out_words (ceil(n_objects/64) words) is
+ * set if sphere j is tested.  Conservative by construction: every sphere such a ray can meet is in the set. */
+int rt_scene_bounce_candidates(const void *scene_blob, size_t blob_bytes, uint32_t from, const double dir[3], uint64_t *out_words);
+
 /* Upload a scene to `device` (index into the GPUs in use) and keep it resident. */
 int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_scene_dev **out);
 void rt_scene_free(rt_scene_dev *scene);

@@ -313,6 +313,35 @@ def test_deinterleave_kernel_wide_and_ragged(lib):
         assert np.array_equal(np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4), want), (w, h, tile_rows, G)
 
 
+@pytest.mark.parametrize("seed,n,refract,segs", [
+    (31, 30, False, 5), (32, 64, False, 6), (33, 100, True, 5), (34, 200, False, 4), (35, 40, True, 8), (36, 26, True, 3)])
+def test_bounce_table_is_exact(lib, seed, n, refract, segs):
+    """Scenes with more than 24 spheres in the loops prune the closest-hit search of reflected and refracted rays with the
+    bounce table (per sphere and direction cell, the spheres a ray leaving that sphere can meet).  The table only prunes:
+    the image must match the C restatement, which scans every sphere - with reflection chains, refraction trees (rays
+    that start on the INSIDE of a sphere, parked two-child nodes), more than 64 spheres (multi-word sets), and tiny
+    frames where a wave's rays fan out over many cells (the scan-everything fallback)."""
+    s = random_scene(seed, n, refract, segs)
+    blob = rt_host.flatten_scene(s)
+    for w, h in ((192, 128), (24, 16)):
+        got = gpu_frame(lib, blob, w, h)
+        want = ou.c_oracle_render(blob, w, h)
+        assert ou.max_lsb(got, want)[0] <= 1, (seed, w, h)
+    # and it is the table's doing: with the table switched off the frame is the same
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import hashlib, rt_host, test_gpu_parity as T;"
+            "lib = rt_host.load_library(); assert lib.rt_init(1) == 0;"
+            "b = rt_host.flatten_scene(T.random_scene(%d, %d, %r, %d)); print(hashlib.sha256(T.gpu_frame(lib, b, 192, 128)).hexdigest())"
+            % (os.path.join(ou.ROOT, "html5-canvas-raytracer_amd"), os.path.join(ou.ROOT, "tests"), seed, n, refract, segs))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, RT_NO_BOUNCE_TABLE="1"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    import hashlib
+    assert r.stdout.strip().splitlines()[-1] == hashlib.sha256(gpu_frame(lib, blob, 192, 128)).hexdigest()
+
+
 def gpu_tiles_rgb24(lib, scene, w, h, tiles, flags=0, n_frames=1):
     """The same tiles with RT_FLAG_RGB24: n_frames bands of w*3 bytes per row."""
     r = rt_host.Renderer(scene, 0, lib)

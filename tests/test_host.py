@@ -214,3 +214,62 @@ def test_validator_survives_corrupted_blobs(built):
                 accepted += 1
                 assert lib.rt_scene_cull_rects(buf, len(b), out) == 0
         assert accepted > 0
+
+
+def test_bounce_table_is_conservative(built):
+    """Host logic of the product kernel's bounce table (rt_scene_bounce_candidates): rays that start ON a sphere (on its
+    outside or its inside surface) in random directions - every sphere such a ray actually meets in front of its origin
+    must be in the candidate set of (sphere, direction cell).  Includes overlapping spheres, a sphere inside another,
+    a huge ground and an enclosing sky."""
+    import random
+    import numpy as np
+    lib = rt_host.load_library()
+    rng = random.Random(11)
+    scene = rt_host.load_scene("h8")
+    base = scene["objects"][0]
+    objs = []
+    for k in range(48):
+        r = rng.choice([0.05, 0.3, 0.3, 1.0, 1.0, 4.0])
+        o = dict(base)
+        o["origin"] = [rng.uniform(-6, 6), rng.uniform(-1, 6), rng.uniform(-6, 6)]
+        o["r2"] = r * r
+        objs.append(o)
+    for origin, r in (([0.0, -500.0, 0.0], 500.0), ([0.0, 0.0, 0.0], 5000.0)):
+        o = dict(base)
+        o["origin"], o["r2"] = origin, r * r
+        objs.append(o)
+    scene["objects"] = objs
+    blob = rt_host.flatten_scene(scene)
+    buf = C.create_string_buffer(blob, len(blob))
+    n = len(objs)
+    cen = np.array([o["origin"] for o in objs])
+    r2 = np.array([o["r2"] for o in objs])
+    words = (n + 63) // 64
+    out = (C.c_uint64 * words)()
+    nrng = np.random.default_rng(5)
+    checked = hits = listed = 0
+    for trial in range(1500):
+        i = rng.randrange(n)
+        nrm = nrng.normal(size=3)
+        nrm /= np.linalg.norm(nrm)
+        p = cen[i] + nrm * np.sqrt(r2[i])
+        d = nrng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if trial % 7 == 0:                       # axis-aligned and face-diagonal directions sit on cell edges
+            d = np.array(rng.choice([[1, 0, 0], [0, -1, 0], [0, 0, 1], [1, 1, 0], [-1, 0, 1], [1, -1, 1]]), dtype=float)
+            d /= np.linalg.norm(d)
+        dd = (C.c_double * 3)(*d)
+        assert lib.rt_scene_bounce_candidates(buf, len(blob), i, dd, out) == 0, lib.rt_last_error()
+        mask = [(out[j >> 6] >> (j & 63)) & 1 for j in range(n)]
+        L = cen - p
+        tca = L @ d
+        disc = r2 - ((L * L).sum(axis=1) - tca * tca)
+        thc = np.sqrt(np.maximum(disc, 0.0))
+        met = (disc >= 0) & (tca + thc >= 0.001)          # some root at or beyond the reference's epsilon
+        for j in np.nonzero(met)[0]:
+            assert mask[j], (trial, i, j, d.tolist())
+        checked += 1
+        hits += int(met.sum())
+        listed += sum(mask)
+    assert checked == 1500 and hits > 3000
+    assert listed < 0.75 * checked * n                    # and it does prune (the two giant spheres are always listed)
