@@ -51,6 +51,10 @@ struct device_state {
   size_t frame_bytes = 0;
   void *d_gather = nullptr;              // device 0 only: gather target
   size_t gather_bytes = 0;
+  // rt_render: the scene of the previous call stays resident; a call with the same blob (byte for byte) reuses it
+  // (upload + table builds cost 0.1 ms for 8 spheres and 1.8 ms for 64, against a 0.7 ms frame)
+  struct rt_scene_dev *cached_scene = nullptr;
+  std::vector<uint8_t> cached_blob;
 };
 
 struct lib_state {
@@ -311,26 +315,35 @@ std::vector<uint64_t> build_bounce_table(const rt_sphere *objs, uint32_t n_objec
       ccos[c] = cos(half); csin[c] = sin(half);
     }
   }
+  // per (i, j): one branch-free pass over the cells (structure-of-arrays, no division: both sides scaled by |D|)
+  std::vector<double> cx(cells), cy(cells), cz(cells);
+  for (uint32_t c = 0; c < cells; c++) { cx[c] = cdir[3u * c]; cy[c] = cdir[3u * c + 1]; cz[c] = cdir[3u * c + 2]; }
+  std::vector<uint8_t> hit(cells);
   for (uint32_t i = 0; i < n_objects; i++) {
     const double ri = sqrt(objs[i].r2);
     uint64_t *row = tab.data() + (size_t)i * cells * words;
+    // rays leave a sphere only if it reflects or refracts (albedo[3] > 0 or albedo[4] > 0, main.js:233,246): the rows of
+    // the others are never read
+    if (!(objs[i].albedo[3] > 0.0) && !(objs[i].albedo[4] > 0.0)) continue;
     for (uint32_t j = 0; j < n_loop; j++) {
-      const double D[3] = {objs[j].origin[0] - objs[i].origin[0], objs[j].origin[1] - objs[i].origin[1], objs[j].origin[2] - objs[i].origin[2]};
-      const double Ld = sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+      const double D0 = objs[j].origin[0] - objs[i].origin[0], D1 = objs[j].origin[1] - objs[i].origin[1], D2 = objs[j].origin[2] - objs[i].origin[2];
+      const double Ld = sqrt(D0 * D0 + D1 * D1 + D2 * D2);
       const double R = (ri + sqrt(objs[j].r2)) * (1.0 + 1e-9);
       const uint64_t bit = 1ull << (j & 63u);
+      const size_t wj = j >> 6;
       const bool everywhere = !(R < Ld * (1.0 - 1e-9)) || !std::isfinite(R) || !std::isfinite(Ld);   // overlapping / containing / degenerate: all cells
-      const double sa = everywhere ? 1.0 : R / Ld, ca = everywhere ? 0.0 : sqrt(fmax(0.0, 1.0 - sa * sa));
-      for (uint32_t c = 0; c < cells; c++) {
-        bool cand = everywhere;
-        if (!cand) {
-          // angle(centre, D) <= alpha + half  <=>  cos(angle) >= cos(alpha + half) when alpha + half < pi
-          const double cosang = (cdir[3u * c] * D[0] + cdir[3u * c + 1] * D[1] + cdir[3u * c + 2] * D[2]) / Ld;
-          const double cos_sum = ca * ccos[c] - sa * csin[c], sin_sum = sa * ccos[c] + ca * csin[c];   // alpha, half in (0, pi/2): sum < pi
-          cand = (sin_sum <= 0.0) || (cosang >= cos_sum - 1e-12);
-        }
-        if (cand) row[(size_t)c * words + (j >> 6)] |= bit;
+      if (everywhere) {
+        for (uint32_t c = 0; c < cells; c++) row[(size_t)c * words + wj] |= bit;
+        continue;
       }
+      const double sa = R / Ld, ca = sqrt(fmax(0.0, 1.0 - sa * sa));
+      // angle(centre, D) <= alpha + half  <=>  cos(angle) >= cos(alpha + half); alpha, half in (0, pi/2), so the sum is < pi
+      for (uint32_t c = 0; c < cells; c++) {
+        const double dotp = cx[c] * D0 + cy[c] * D1 + cz[c] * D2;                       // |D| cos(angle)
+        const double cos_sum = ca * ccos[c] - sa * csin[c], sin_sum = sa * ccos[c] + ca * csin[c];
+        hit[c] = (uint8_t)((sin_sum <= 0.0) | (dotp >= Ld * (cos_sum - 1e-12)));
+      }
+      for (uint32_t c = 0; c < cells; c++) if (hit[c]) row[(size_t)c * words + wj] |= bit;
     }
   }
   return tab;
@@ -775,6 +788,20 @@ int ensure_rccl(int ndev) {
   return RT_OK;
 }
 
+// rt_render's scene for `device`: the resident one if the blob is the same bytes, else a fresh upload that replaces it.
+int scene_for(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
+  device_state &D = G.dev[device];
+  if (D.cached_scene && D.cached_blob.size() == bytes && memcmp(D.cached_blob.data(), blob, bytes) == 0) { *out = D.cached_scene; return RT_OK; }
+  if (D.cached_scene) { rt_scene_free(D.cached_scene); D.cached_scene = nullptr; D.cached_blob.clear(); }
+  rt_scene_dev *s = nullptr;
+  const int rc = rt_scene_upload(device, blob, bytes, &s);
+  if (rc) return rc;
+  D.cached_scene = s;
+  D.cached_blob.assign((const uint8_t *)blob, (const uint8_t *)blob + bytes);
+  *out = s;
+  return RT_OK;
+}
+
 int ensure_frame(device_state &D, size_t bytes) {
   if (D.frame_bytes >= bytes) return RT_OK;
   if (D.d_frame) (void)hipFree(D.d_frame);
@@ -802,7 +829,7 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
     // ---- one GPU.  Large frames are rendered as a few row bands so that the PCIe copy-out of band i (copy
     //      stream) runs while band i+1 renders (render stream): the frame costs ~max(render, copy), not the sum ----
     rt_scene_dev *s = nullptr;
-    if ((rc = rt_scene_upload(0, blob, bytes, &s))) return rc;
+    if ((rc = scene_for(0, blob, bytes, &s))) return rc;
     device_state &D = G.dev[0];
     rc = ensure_frame(D, frame_bytes);
     if (!rc && !D.copy_stream) {
@@ -853,7 +880,6 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
       }
       agg = st;
     }
-    rt_scene_free(s);
     if (rc) return rc;
   } else {
     // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
@@ -869,10 +895,10 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
     std::vector<rt_scene_dev *> scenes(ndev, nullptr);
     rc = RT_OK;
     for (int g = 0; g < ndev && !rc; g++) {
-      rc = rt_scene_upload(g, blob, bytes, &scenes[g]);
+      rc = scene_for(g, blob, bytes, &scenes[g]);
       if (!rc) rc = ensure_frame(G.dev[g], band_bytes);
     }
-    if (!rc) {                                   // (no early returns below: the scenes are freed at the end)
+    if (!rc) {                                   // (the scenes stay cached on their devices)
       device_state &R = G.dev[0];
       hipError_t e = hipSetDevice(R.hip_id);
       if (e == hipSuccess && R.gather_bytes < band_bytes * ndev + frame_bytes) {
@@ -927,7 +953,6 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
       }
       if (ev0[g]) (void)hipEventDestroy(ev0[g]);
       if (ev1[g]) (void)hipEventDestroy(ev1[g]);
-      rt_scene_free(scenes[g]);
     }
     if (rc) return rc;
     agg.pixels = (uint64_t)w * h;
@@ -950,6 +975,7 @@ extern "C" void rt_shutdown(void) {
     if (!D.stream) continue;
     (void)hipSetDevice(D.hip_id);
     (void)hipStreamSynchronize(D.stream);
+    if (D.cached_scene) rt_scene_free(D.cached_scene);
     if (D.d_frame) (void)hipFree(D.d_frame);
     if (D.d_gather) (void)hipFree(D.d_gather);
     if (D.d_counters) (void)hipFree(D.d_counters);

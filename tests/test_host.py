@@ -233,10 +233,12 @@ def test_bounce_table_is_conservative(built):
         o = dict(base)
         o["origin"] = [rng.uniform(-6, 6), rng.uniform(-1, 6), rng.uniform(-6, 6)]
         o["r2"] = r * r
+        o["mtl"] = dict(base["mtl"], albedo=[0.0, 0.5, 0.5, 0.5 if k % 2 else 0.0, 0.0 if k % 2 else 0.8])   # every sphere spawns rays
         objs.append(o)
     for origin, r in (([0.0, -500.0, 0.0], 500.0), ([0.0, 0.0, 0.0], 5000.0)):
         o = dict(base)
         o["origin"], o["r2"] = origin, r * r
+        o["mtl"] = dict(base["mtl"], albedo=[0.0, 0.5, 0.5, 0.3, 0.0])
         objs.append(o)
     scene["objects"] = objs
     blob = rt_host.flatten_scene(scene)
