@@ -561,6 +561,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             }
 #ifdef RT_ABLATE_SHADOW
             const uint32_t NS = 0;
+#elif defined(RT_ABLATE_SHADOW4)
+            const uint32_t NS = NLOOP > 4u ? NLOOP - 4u : NLOOP;      // timing only: what skipping four tests per light would be worth
 #else
             const uint32_t NS = NLOOP;
 #endif
