@@ -61,6 +61,7 @@ struct lib_state {
   bool inited = false;
   std::vector<device_state> dev;
   std::mutex mu;
+  std::mutex dev_mu;                     // lazy per-device stream creation (ensure_device may run inside rt_render, which holds `mu`)
   // RCCL, resolved lazily with dlopen so that single-GPU users never load it
   void *rccl = nullptr;
   void *comms[16] = {nullptr};
@@ -77,9 +78,12 @@ int ensure_device(int d) {
   if (d < 0 || d >= (int)G.dev.size()) return fail(RT_ERR_INVALID, "device %d out of range (0..%d)", d, (int)G.dev.size() - 1);
   device_state &s = G.dev[d];
   HIP_TRY(hipSetDevice(s.hip_id));
+  std::lock_guard<std::mutex> lk(G.dev_mu);
   if (!s.stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    hipStream_t st = nullptr;
     HIP_TRY(hipMalloc(&s.d_counters, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    s.stream = st;                         // published last: a non-NULL stream means the device state is complete
   }
   return RT_OK;
 }

@@ -12,6 +12,11 @@
  * success and a negative rt_status on failure; rt_last_error() describes the failure
  * of the calling thread's last call.
  *
+ * Threads: rt_init, rt_shutdown and rt_render serialise on an internal lock.  The device entry points
+ * (rt_scene_upload, rt_render_tiles_device, rt_render_batch_device, rt_deinterleave_*) may be called from several
+ * threads at once; work on one HIP stream is ordered by the stream.  Launches with RT_FLAG_COUNT share one counter
+ * buffer per device: one at a time per device.
+ *
  * The scene crosses the boundary as ONE contiguous, pointer-free blob
  * (rt_scene_header followed by the tables it gives offsets to), so any host language
  * can build it with typed arrays and the library can upload it with one copy.

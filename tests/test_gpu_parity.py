@@ -342,6 +342,33 @@ def test_bounce_table_is_exact(lib, seed, n, refract, segs):
     assert r.stdout.strip().splitlines()[-1] == hashlib.sha256(gpu_frame(lib, blob, 192, 128)).hexdigest()
 
 
+def test_device_entry_points_from_concurrent_threads(lib):
+    """include/rt_hip.h: the device entry points may be called from several threads at once.  Four threads, each with its
+    own scene, renderer and output buffer (ctypes releases the GIL during the calls), render repeatedly; every frame must
+    equal the one the same scene gives when rendered alone."""
+    import threading
+    cases = [("h8", 320, 180), ("default14", 200, 120), ("lcg64_ss1", 160, 96), ("cfg2", 256, 144)]
+    blobs = [rt_host.flatten_scene(rt_host.load_scene(n)) for n, _, _ in cases]
+    want = [gpu_frame(lib, b, w, h) for b, (_, w, h) in zip(blobs, cases)]
+    errors = []
+
+    def worker(i):
+        try:
+            _, w, h = cases[i]
+            for _ in range(6):
+                if gpu_frame(lib, blobs[i], w, h) != want[i]:
+                    errors.append((i, "frame differs"))
+        except Exception as e:      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def gpu_tiles_rgb24(lib, scene, w, h, tiles, flags=0, n_frames=1):
     """The same tiles with RT_FLAG_RGB24: n_frames bands of w*3 bytes per row."""
     r = rt_host.Renderer(scene, 0, lib)
