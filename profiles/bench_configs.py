@@ -11,7 +11,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "html5-canvas-raytracer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
 import oracle_util as ou
 import rt_host
 
