@@ -100,11 +100,17 @@ def main():
     # RT_BENCH_REHEARSE=1: rehearsal of the N>1 control flow on a ONE-GPU box — every rank shares GPU 0 and
     # the exchange goes over gloo through host memory.  Never a measurement (the JSON says so).
     rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
+    # RT_BENCH_FORCE_EXCHANGE=1 (N=1 only): run the N>1 code path with ONE rank - RGB24 tiles, a real 1-rank RCCL
+    # all_to_all_single (a self copy), the side stream, the de-interleave.  It measures what the plan itself costs (host
+    # issue time, copy kernels and de-interleave competing with the render) on a one-GPU box; the JSON says so.
+    force = world == 1 and os.environ.get("RT_BENCH_FORCE_EXCHANGE") == "1"
+    multi = world > 1 or force
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -120,12 +126,15 @@ def main():
     # N>1: the bands cross xGMI as RGB24 (the alpha byte is the constant 255, main.js:198; the de-interleave on the
     # receiving rank restores it) — a quarter less link time, which is what bounds N=2 and N=4.
     # RT_BENCH_RGBA_EXCHANGE=1 ships RGBA8 instead (A/B).
-    channels = 3 if (world > 1 and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+    channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
     plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
     batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
     # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
-    tstream = torch.cuda.Stream(device=dev)
+    # N>1: the render stream gets HIGH priority, so the exchange's copy kernels and the de-interleave (normal priority,
+    # memory-bound) fill in around the render instead of competing with it for wave slots (RT_BENCH_NO_PRIORITY=1: A/B)
+    hi_prio = multi and os.environ.get("RT_BENCH_NO_PRIORITY") != "1"
+    tstream = torch.cuda.Stream(device=dev, priority=-1) if hi_prio else torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
@@ -133,18 +142,18 @@ def main():
     # ~60-150 us of host time to issue (measured: 57 us for a 1-rank all_to_all_single), about as much as a step's GPU
     # work, so issuing one per step would make the job host-bound; per-GPU work per STEP stays one frame's worth of
     # pixels at every N, the bands of `every` steps travel together (larger messages also use the links better).
-    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "4"))) if world > 1 else 1
+    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "4"))) if multi else 1
     frames = torch.empty((every, h, w, 4), dtype=torch.uint8, device=dev)   # the frames this rank reassembles (N=1: the frame)
     frame = frames[0]
     # Opt-in (RT_BENCH_TWO_STREAMS=1, N=1): consecutive frames alternate between two HIP streams and two frame
     # buffers, so the tail of frame k overlaps the head of frame k+1 (+3 % measured).  Off by default so that
     # every launch of the timed region runs alone and rocprof's per-kernel average equals `kernel_ms`.
-    two_streams = world == 1 and os.environ.get("RT_BENCH_TWO_STREAMS") == "1"
+    two_streams = not multi and os.environ.get("RT_BENCH_TWO_STREAMS") == "1"
     frame_b = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if two_streams else None
     tstream_b = torch.cuda.Stream(device=dev) if two_streams else None
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
-    if world > 1:
+    if multi:
         # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
         send = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
         recv = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -153,11 +162,11 @@ def main():
     group = {"slot": 0, "fill": 0}                                 # the exchange buffer being filled, and how many steps are in it
     # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
     # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
-    slot_free = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if multi else None
+    slot_free = [torch.cuda.Event() for _ in range(2)] if multi else None
 
     def render_step(slot, j=0):
-        if world == 1:
+        if not multi:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
         else:   # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
             renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
@@ -183,7 +192,7 @@ def main():
         group["slot"], group["fill"] = slot ^ 1, 0
 
     def step(k):
-        if world == 1:
+        if not multi:
             if two_streams and (k & 1):
                 renderer.render_tiles(w, h, frame_b.data_ptr(), whole, stream=tstream_b.cuda_stream, flags=flags)
             else:
@@ -197,14 +206,14 @@ def main():
             launch_exchange()
 
     def drain():
-        if world > 1 and group["fill"] > 0:                      # a partial group still travels (whole buffer; only its steps count)
+        if multi and group["fill"] > 0:                      # a partial group still travels (whole buffer; only its steps count)
             launch_exchange()
         while pending:
             finish(pending.pop(0))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -237,7 +246,7 @@ def main():
         b.record()
     torch.cuda.synchronize()
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-    launch_pixels = w * h if world == 1 else world * plan.pixels_of(rank)
+    launch_pixels = w * h if not multi else world * plan.pixels_of(rank)
 
     # one more (untimed) step; EVERY rank checks the frame it reassembled against the rows the reference itself
     # rendered (tests/golden, fixtures - not the oracle), and the worst rank is reported
@@ -276,7 +285,7 @@ def main():
             key = "%s_%dx%d" % (args.scene, w, h)
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
-        if world == 1:
+        if not multi:
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
         else:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
@@ -290,7 +299,8 @@ def main():
             "config": {"workload": "%s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; %s" % (
                 args.scene, len(scene["objects"]), len(scene["lights"]), scene["segs"], ss, w, h, how),
                 "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step, "pixels_per_gpu_per_step": w * h,
-                **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {})},
+                **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {}),
+                **({"FORCED_EXCHANGE": "the N>1 plan run by ONE rank (1-rank RCCL all-to-all = self copy): the plan's own overhead, not the headline"} if force else {})},
             "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
             "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
             "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok,
@@ -301,7 +311,7 @@ def main():
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
                           "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
         }
-        if world > 1:
+        if multi:
             out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
                                "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
                                "steps_per_collective": every}
@@ -313,7 +323,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     renderer.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:      # a fast frame that differs from the reference's is not a result

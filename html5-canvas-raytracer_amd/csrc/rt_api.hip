@@ -527,9 +527,30 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   return rt_render_batch_device(s, w, h, tiles, 1u, d_out, 0u, hip_stream, flags, stats);
 }
 
+namespace {
+int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
+                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats);
+}  // namespace
+
 extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out,
                                       uint64_t frame_stride_bytes, void *hip_stream, uint32_t flags, rt_stats *stats) {
-  if (!s || !tiles || !d_out) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
+  if (!d_out) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
+  return render_batch_impl(s, w, h, tiles, n_frames, d_out, frame_stride_bytes, nullptr, hip_stream, flags, stats);
+}
+
+extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *const *d_frames,
+                                        void *hip_stream, uint32_t flags, rt_stats *stats) {
+  if (!d_frames) return fail(RT_ERR_INVALID, "NULL frame pointer array");
+  if (n_frames == 0 || n_frames > RT_MAX_SCATTER) return fail(RT_ERR_INVALID, "scatter: n_frames %u not in 1..%u", n_frames, RT_MAX_SCATTER);
+  if (flags & RT_FLAG_RGB24) return fail(RT_ERR_INVALID, "scatter writes whole RGBA8 frames: RT_FLAG_RGB24 does not apply");
+  for (uint32_t f = 0; f < n_frames; f++) if (!d_frames[f] || ((uintptr_t)d_frames[f] & 3u)) return fail(RT_ERR_INVALID, "scatter: frame pointer %u is NULL or unaligned", f);
+  return render_batch_impl(s, w, h, tiles, n_frames, nullptr, 0u, d_frames, hip_stream, flags, stats);
+}
+
+namespace {
+int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
+                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats) {
+  if (!s || !tiles) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
   if (n_frames == 0 || n_frames > 65535u) return fail(RT_ERR_INVALID, "n_frames %u not in 1..65535", n_frames);
   if ((frame_stride_bytes & 3u) != 0) return fail(RT_ERR_INVALID, "frame stride must be a multiple of 4 bytes");
   if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "frame size %ux%u not in 1..65536", w, h);
@@ -590,6 +611,8 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
   L.n_frames = n_frames;
   L.frame_stride = frame_stride_bytes / 4u;
   L.rgb24 = (flags & RT_FLAG_RGB24) ? 1u : 0u;
+  L.scatter = d_frames ? 1u : 0u;
+  if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
@@ -623,6 +646,39 @@ extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
     }
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
+  return RT_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------ sharing memory between the ranks of a node
+extern "C" int rt_ipc_export(int device, const void *d_ptr, void *handle_out) {
+  static_assert(sizeof(hipIpcMemHandle_t) == RT_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is expected to be 64 bytes");
+  if (!d_ptr || !handle_out) return fail(RT_ERR_INVALID, "rt_ipc_export: NULL argument");
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  hipIpcMemHandle_t hnd;
+  HIP_TRY(hipIpcGetMemHandle(&hnd, const_cast<void *>(d_ptr)));
+  memcpy(handle_out, &hnd, sizeof hnd);
+  return RT_OK;
+}
+
+extern "C" int rt_ipc_open(int device, const void *handle, void **d_ptr_out) {
+  if (!handle || !d_ptr_out) return fail(RT_ERR_INVALID, "rt_ipc_open: NULL argument");
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  hipIpcMemHandle_t hnd;
+  memcpy(&hnd, handle, sizeof hnd);
+  void *p = nullptr;
+  HIP_TRY(hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess));
+  *d_ptr_out = p;
+  return RT_OK;
+}
+
+extern "C" int rt_ipc_close(int device, void *d_ptr) {
+  if (!d_ptr) return RT_OK;
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  HIP_TRY(hipIpcCloseMemHandle(d_ptr));
   return RT_OK;
 }
 

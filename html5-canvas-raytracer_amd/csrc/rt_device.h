@@ -17,6 +17,7 @@
 
 // Shadow grid (product kernel, scenes with more than RT_SGRID_MIN_LOOP spheres in the loops): cells per axis of a
 // light's projective view of the scene; see build_shadow_grid in rt_api.hip for the buffer layout.
+#define RT_MAX_SCATTER 16u          /* frames of one rt_render_scatter_device call */
 #define RT_SGRID 32u
 #define RT_SGRID_MIN_LOOP 12u
 // Bounce table (same scenes): directions are binned on a cube map of RT_BGRID x RT_BGRID cells per face; see
@@ -61,6 +62,9 @@ struct rt_launch {
   uint32_t enclosing;                // device index (== n_loop, the table's last entry) of a sphere that strictly contains
                                      // every other sphere, every light and the camera; ~0u if none or not used
   uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
+  uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
+                                     // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
+  uint32_t *out_frames[RT_MAX_SCATTER];
 };
 
 #endif

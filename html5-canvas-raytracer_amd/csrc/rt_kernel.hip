@@ -908,7 +908,11 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t frame_i = blockIdx.z;
   const bool valid = P1.valid;
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
-  uint32_t *__restrict__ out = L.out + (size_t)frame_i * L.frame_stride;
+  // scatter: every frame of the batch has its own destination (the frame buffer of the rank that owns it, peer-mapped
+  // over xGMI) and rows go to their place in the FRAME, so nothing is left to exchange or to de-interleave; a tile row
+  // is whole 128-byte lines written by one workgroup, which is what a remote store wants
+  uint32_t *__restrict__ out = L.scatter ? L.out_frames[frame_i] : L.out + (size_t)frame_i * L.frame_stride;
+  const uint32_t orow = L.scatter ? P1.frow : P1.lrow;
   uint32_t rgbw;                                       // this lane's pixel as 0x00BBGGRR
   if (!SS2) rgbw = r8 | (g8 << 8) | (b8 << 16);
   else {
@@ -920,7 +924,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     rgbw = (((packed & 1023u) + 2u) >> 2) | ((((packed >> 10) & 1023u) + 2u) >> 2 << 8) | ((((packed >> 20) & 1023u) + 2u) >> 2 << 16);
   }
   if (!L.rgb24) {                                      // wave-uniform
-    if (valid && P1.sub == 0u) out[P1.lrow * L.w + P1.px] = rgbw | 0xff000000u;   // a band holds < 2^32 pixels (host check)
+    if (valid && P1.sub == 0u) out[(size_t)orow * L.w + P1.px] = rgbw | 0xff000000u;
   } else {
     // RT_FLAG_RGB24: the 8 pixels a wave holds of one row are 24 bytes = 6 words.  Word j of the group takes its bytes
     // from pixels p = j + j/3 and p + 1, shifted by (j mod 3) bytes; lanes j < 6 of the group store.  w % 4 == 0 (host

@@ -157,6 +157,11 @@ ABI = {
     "rt_copy_to_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rt_deinterleave_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint64, C.c_void_p]),
+    "rt_render_scatter_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p,
+                                           C.c_uint32, C.POINTER(RtStats)]),
+    "rt_ipc_export": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_ipc_open": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_ipc_close": (C.c_int, [C.c_int, C.c_void_p]),
     "rt_deinterleave_rgb24_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_uint64, C.c_void_p]),
 }
@@ -222,6 +227,17 @@ class Renderer:
         rc = self.lib.rt_render_batch_device(self.handle, w, h, C.byref(t), n_frames, C.c_void_p(d_out), frame_stride_bytes,
                                              C.c_void_p(stream or 0), flags, C.byref(st) if st is not None else None)
         _check(self.lib, rc, "rt_render_batch_device")
+        return st
+
+    def render_scatter(self, w, h, frame_ptrs, tiles, stream=None, flags=0, want_stats=False):
+        """`tiles` of len(frame_ptrs) frames in ONE launch; frame f's rows go to their place in the whole RGBA8 frame at
+        frame_ptrs[f] (which may be another GPU's memory, peer-mapped with rt_ipc_open)."""
+        t = tiles if isinstance(tiles, RtTiles) else RtTiles(*tiles)
+        st = RtStats() if want_stats else None
+        arr = (C.c_void_p * len(frame_ptrs))(*frame_ptrs)
+        rc = self.lib.rt_render_scatter_device(self.handle, w, h, C.byref(t), len(frame_ptrs), arr, C.c_void_p(stream or 0), flags,
+                                               C.byref(st) if st is not None else None)
+        _check(self.lib, rc, "rt_render_scatter_device")
         return st
 
     def close(self):

@@ -178,6 +178,22 @@ int rt_render_tiles_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt
 int rt_render_batch_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames,
                            void *d_out_rgba, uint64_t frame_stride_bytes, void *hip_stream, uint32_t flags, rt_stats *stats);
 
+/* The same batch with one destination PER FRAME: frame f's tiles are written into d_frames[f], a whole w x h RGBA8
+ * frame buffer, at their rows of the FRAME (not contiguously as a band).  d_frames is a HOST array of n_frames
+ * (<= 16) device pointers; they may point into other GPUs' memory (peer-mapped, e.g. opened with rt_ipc_open): on an
+ * xGMI node every rank then stores its tiles of frame f straight into the memory of the rank that owns frame f, and
+ * no exchange or de-interleave pass is left - only a barrier.  RGBA8 only (no RT_FLAG_RGB24). */
+int rt_render_scatter_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames,
+                             void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats);
+
+/* Sharing a device allocation between the processes of one node (one process per GPU): rt_ipc_export fills a 64-byte
+ * handle for memory obtained from rt_alloc_device (the pointer must be the allocation's base); rt_ipc_open maps it in
+ * another process for `device` (with peer access over xGMI when it lives on another GPU) and rt_ipc_close unmaps it. */
+#define RT_IPC_HANDLE_BYTES 64u
+int rt_ipc_export(int device, const void *d_ptr, void *handle_out);
+int rt_ipc_open(int device, const void *handle, void **d_ptr_out);
+int rt_ipc_close(int device, void *d_ptr);
+
 /* render(width,height,scene): whole frame into HOST memory (any host pointer; memory from
  * rt_alloc_pinned makes the copy-out DMA directly).  With more than one GPU in use the
  * frame is sharded by interleaved row tiles and reassembled on GPU 0 with one RCCL gather

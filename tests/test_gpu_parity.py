@@ -369,6 +369,79 @@ def test_device_entry_points_from_concurrent_threads(lib):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("scene,w,h,G,tile_rows", [("h8", 320, 200, 3, 16), ("default14", 131, 77, 2, 8), ("lcg64", 96, 50, 4, 8)])
+def test_scatter_writes_every_frame_in_place(lib, scene, w, h, G, tile_rows):
+    """rt_render_scatter_device (the peer-store plan): rank g writes its interleaved tiles of EVERY frame of the batch
+    straight into that frame's own buffer, rows at their place in the frame.  After all G "ranks" have launched, each of
+    the G frame buffers holds the whole frame - no exchange, no de-interleave - and nothing outside them was touched."""
+    import shard
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    want = gpu_frame(lib, blob, w, h)
+    plan = shard.TilePlan(w, h, tile_rows, G)
+    n = w * h * 4
+    pad = 256
+    base = lib.rt_alloc_device(0, G * (n + pad))
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemset(C.c_void_p(base), 0x5A, C.c_size_t(G * (n + pad))) == 0
+    ptrs = [base + f * (n + pad) for f in range(G)]
+    r = rt_host.Renderer(blob, 0, lib)
+    try:
+        for g in range(G):
+            r.render_scatter(w, h, ptrs, rt_host.RtTiles(*plan.rt_tiles(g)), want_stats=True)
+        host = C.create_string_buffer(G * (n + pad))
+        assert lib.rt_copy_to_host(0, host, base, G * (n + pad)) == 0
+    finally:
+        r.close()
+        lib.rt_free_device(0, base)
+    for f in range(G):
+        assert host.raw[f * (n + pad):f * (n + pad) + n] == want, (scene, f)
+        assert host.raw[f * (n + pad) + n:(f + 1) * (n + pad)] == b"\x5a" * pad
+    # argument checks
+    r = rt_host.Renderer(blob, 0, lib)
+    try:
+        with pytest.raises(RuntimeError):
+            r.render_scatter(w, h, [0], rt_host.RtTiles(h, 0, 1, 1))
+        with pytest.raises(RuntimeError):
+            r.render_scatter(w, h, [4096] * 17, rt_host.RtTiles(h, 0, 1, 1))
+    finally:
+        r.close()
+
+
+def test_ipc_peer_process_renders_into_our_frame(lib):
+    """rt_ipc_export / rt_ipc_open: a second PROCESS maps this process's frame buffer and scatters its half of the tiles
+    into it while this process renders the other half - what two ranks of a node do to each other over xGMI (here both
+    on the one GPU of the box).  The frame must be the whole frame."""
+    import os
+    import subprocess
+    import sys
+    import shard
+    scene, w, h = "h8", 640, 360
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    want = gpu_frame(lib, blob, w, h)
+    plan = shard.TilePlan(w, h, 16, 2)
+    n = w * h * 4
+    d = lib.rt_alloc_device(0, n)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemset(C.c_void_p(d), 0, C.c_size_t(n)) == 0
+    handle = C.create_string_buffer(64)
+    assert lib.rt_ipc_export(0, d, handle) == 0, lib.rt_last_error()
+    r = rt_host.Renderer(blob, 0, lib)
+    try:
+        cmd = [sys.executable, os.path.join(ou.ROOT, "tests", "ipc_child.py"), handle.raw.hex(), scene, str(w), str(h)] + [str(v) for v in plan.rt_tiles(1)]
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        r.render_scatter(w, h, [d], rt_host.RtTiles(*plan.rt_tiles(0)), want_stats=True)
+        out, err = child.communicate(timeout=300)
+        assert child.returncode == 0 and "IPC_CHILD_DONE" in out, err[-2000:]
+        host = C.create_string_buffer(n)
+        assert lib.rt_copy_to_host(0, host, d, n) == 0
+    finally:
+        r.close()
+        lib.rt_free_device(0, d)
+    assert host.raw == want
+
+
 def gpu_tiles_rgb24(lib, scene, w, h, tiles, flags=0, n_frames=1):
     """The same tiles with RT_FLAG_RGB24: n_frames bands of w*3 bytes per row."""
     r = rt_host.Renderer(scene, 0, lib)
