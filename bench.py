@@ -11,18 +11,28 @@ N = 1: a step is ONE kernel launch writing one 3840x2160 frame (the hot path, ma
 
 N > 1 (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI): a step is a BATCH of N
 frames.  Each frame is sharded by interleaved 16-row tiles across the N ranks; every rank renders its
-tiles of all N frames in one launch (rt_render_batch_device), ONE all-to-all sends the band of frame f to
-rank f, and each rank de-interleaves one whole frame in its own HBM.  Per-GPU work per step is one frame's
-worth of pixels at every N (weak scaling), every frame is reassembled by a single RCCL collective, and the
-collective uses all N(N-1) directed xGMI links at once (a gather to one root would be bound by that
-root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels, three links' worth).  The bands
-cross the links as RGB24 — the alpha byte is the constant 255 (main.js:198) and is restored by the
-de-interleave — which takes a quarter off the link time that bounds N=2 and N=4.  The bands of 4 consecutive
-steps (RT_BENCH_EXCHANGE_EVERY) travel in ONE all_to_all_single: issuing a c10d collective costs the host
-about as much time as a step's GPU work (57 us measured for a 1-rank group against a 0.12 ms kernel), so one
-collective per step would leave the job host-bound.  A group's exchange overlaps the renders of the next
-group (two buffer slots).  The scene is resident in HBM
-before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
+tiles of all N frames in one launch, and frame f ends up whole, RGBA8, in rank f's HBM.  Per-GPU work per
+step is one frame's worth of pixels at every N (weak scaling).  Two plans put the frames together:
+
+  * all-to-all (default for N < 6; rt_render_batch_device + ONE all_to_all_single + de-interleave): the bands
+    cross the links as RGB24 - the alpha byte is the constant 255 (main.js:198) and is restored by the
+    de-interleave - a quarter off the link time that bounds N=2 and N=4; the bands of 4 consecutive steps
+    (RT_BENCH_EXCHANGE_EVERY) share one collective, because issuing a c10d collective costs the host about as much
+    as a step's GPU work (57 us measured against a 0.12 ms kernel); a group's exchange overlaps the renders of
+    the next group (two slots, side stream).  Uses all N(N-1) directed links at once (a gather to one root would
+    be bound by that root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels).
+  * peer stores (default for N >= 6; rt_render_scatter_device): every rank's kernel stores its tiles of frame f
+    straight into rank f's frame buffer - peer-mapped once through IPC handles - rows in frame order, RGBA8; a tile
+    row is whole 128-byte lines written by one workgroup.  No data collective, no send/recv buffers, no RCCL copy
+    kernels, no de-interleave: one all_reduce of one int per group of steps is the barrier.  Measured on ONE GPU
+    with one rank (RT_BENCH_FORCE_EXCHANGE=1): the all-to-all plan's own machinery costs 13 % (59 vs 68.7
+    Gpixel/s), the peer-store plan 3 % (66.6).  It ships the alpha byte, so it needs 4.1 MB per link per step at
+    N=8 (33 GB/s, half a link) but would be link-bound below N=6.  Set-up and a one-step PRE-FLIGHT (every rank
+    checks the frame it owns against the reference's rows) run first; any failure on any rank makes all ranks
+    fall back to the all-to-all plan, and the JSON says so.  RT_BENCH_P2P=1/0 forces a plan.
+
+The scene is resident in HBM before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6,
+never here).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the HBM-store roofline the
 metric names (4 algorithmic bytes per pixel); the path is FP64-VALU bound, so `fp64_valu` prices it
@@ -126,7 +136,12 @@ def main():
     # N>1: the bands cross xGMI as RGB24 (the alpha byte is the constant 255, main.js:198; the de-interleave on the
     # receiving rank restores it) — a quarter less link time, which is what bounds N=2 and N=4.
     # RT_BENCH_RGBA_EXCHANGE=1 ships RGBA8 instead (A/B).
-    channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+    # Which plan reassembles the frames (see below): peer stores when a rank's share of a frame per link is small enough
+    # not to be link-bound (N >= 6: 4.1 MB per link per step at N=8 against 12.4 MB of RGB24 at N=2), else the all-to-all
+    # with RGB24 bands, which ships a quarter fewer bytes.  RT_BENCH_P2P=1 / 0 forces one or the other.
+    p2p_env = os.environ.get("RT_BENCH_P2P")
+    p2p = multi and (p2p_env == "1" or (p2p_env is None and world >= 6))
+    channels = 3 if (multi and not p2p and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
     plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
     batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
@@ -153,7 +168,86 @@ def main():
     tstream_b = torch.cuda.Stream(device=dev) if two_streams else None
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
-    if multi:
+    # RT_BENCH_P2P=1 (opt-in, N>1): the PEER-STORE plan.  No data collective: every rank's kernel stores its tiles of frame f
+    # straight into rank f's frame buffer (peer-mapped once through IPC handles; rt_render_scatter_device), rows in frame
+    # order, RGBA8 - and one tiny all_reduce per group of steps is the barrier that says "the group's frames are whole".
+    # No send/recv buffers, no RCCL copy kernels, no de-interleave pass (the all-to-all plan's own overhead is 13 % on one
+    # GPU, RT_BENCH_FORCE_EXCHANGE).  Opt-in because a one-GPU box cannot exercise real xGMI peer stores.
+    frame_bytes = w * h * 4
+    p2p_note = None
+    if p2p:
+        # Set-up and PRE-FLIGHT of the peer-store plan; anything that goes wrong on any rank (no IPC, no peer access, a frame
+        # that does not match the reference's rows) makes every rank fall back to the all-to-all plan, and the JSON says so.
+        import ctypes as C
+        import numpy as np
+        import oracle_util as ou0
+        my_buf, peer_buf, problem = None, [], None
+        try:
+            my_buf = lib.rt_alloc_device(dev_index, 2 * every * frame_bytes)      # [slot][step of the group] whole frames
+            if not my_buf:
+                raise RuntimeError("rt_alloc_device: " + lib.rt_last_error().decode())
+            hnd = C.create_string_buffer(64)
+            if lib.rt_ipc_export(dev_index, my_buf, hnd) != 0:
+                raise RuntimeError("rt_ipc_export: " + lib.rt_last_error().decode())
+            mine = hnd.raw
+            if os.environ.get("RT_BENCH_P2P_INJECT_FAILURE") == str(rank):     # test hook for the fallback
+                raise RuntimeError("injected failure on rank %d" % rank)
+        except Exception as e:      # noqa: BLE001
+            problem, mine = repr(e), None
+        handles = [None] * world
+        dist.all_gather_object(handles, mine)
+        if problem is None and any(x is None for x in handles):
+            problem = "another rank could not export its buffer"
+        if problem is None:
+            try:
+                for g in range(world):
+                    if g == rank:
+                        peer_buf.append(my_buf)
+                    else:
+                        q = C.c_void_p()
+                        hb = C.create_string_buffer(handles[g], 64)
+                        if lib.rt_ipc_open(dev_index, hb, C.byref(q)) != 0:
+                            raise RuntimeError("rt_ipc_open(rank %d): %s" % (g, lib.rt_last_error().decode()))
+                        peer_buf.append(q.value)
+            except Exception as e:      # noqa: BLE001
+                problem = repr(e)
+        oks = [None] * world
+        dist.all_gather_object(oks, problem)
+        if all(x is None for x in oks):
+            # pre-flight: one step through the peer stores, then every rank checks the frame it owns
+            lib.rt_memset_device(dev_index, my_buf, 0, frame_bytes)
+            dist.barrier()
+            renderer.render_scatter(w, h, list(peer_buf), my_tiles, flags=flags, want_stats=True)     # returns when the launch is done
+            dist.barrier()
+            worst = 0
+            host = np.empty((h, w, 4), dtype=np.uint8)
+            lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf, frame_bytes)
+            for f in ou0.manifest()["frames"]:
+                if f["scene"] == args.scene and (f["w"], f["h"]) == (w, h) and f["rows"]:
+                    worst = max(worst, int(ou0.max_lsb(np.ascontiguousarray(host[f["rows"]]).reshape(-1), ou0.golden_frame(f))[0]))
+            if not (host[..., 3] == 255).all():
+                worst = max(worst, 255)                                # a row nobody wrote
+            worsts = [None] * world
+            dist.all_gather_object(worsts, worst)
+            if max(worsts) > 1:
+                oks = ["pre-flight frame differs from the reference's rows by %d LSB" % max(worsts)]
+        if not all(x is None for x in oks):
+            p2p_note = "peer-store plan not usable (%s): all-to-all plan used instead" % next(x for x in oks if x is not None)
+            if rank == 0:
+                print("bench.py: " + p2p_note, file=sys.stderr, flush=True)
+            for g, q in enumerate(peer_buf):
+                if g != rank:
+                    lib.rt_ipc_close(dev_index, q)
+            dist.barrier()
+            if my_buf:
+                lib.rt_free_device(dev_index, my_buf)
+            p2p = False
+            channels = 3 if (w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+            plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
+            batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
+        else:
+            token = torch.zeros(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+    if multi and not p2p:
         # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
         send = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
         recv = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -168,14 +262,19 @@ def main():
     def render_step(slot, j=0):
         if not multi:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
+        elif p2p:   # frame f of this step -> rank f's buffer, slot `slot`, position j; rows in frame order
+            off = (slot * every + j) * frame_bytes
+            renderer.render_scatter(w, h, [b + off for b in peer_buf], my_tiles, stream=stream, flags=flags)
         else:   # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
             renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
 
     def finish(item):
         work, slot, count = item
         with torch.cuda.stream(side):
-            work.wait()                                          # the side stream waits for the exchange
-            if rehearse:
+            work.wait()                                          # the side stream waits for the exchange (p2p: the barrier)
+            if p2p:
+                count = 0                                        # the frames are already whole, in place
+            elif rehearse:
                 recv[slot].copy_(host_recv)
             for j in range(count):                               # one whole frame per step of the group ends up on this rank
                 shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
@@ -184,11 +283,16 @@ def main():
 
     def launch_exchange():
         slot = group["slot"]
-        if rehearse:
+        if p2p:
+            if rehearse:
+                torch.cuda.synchronize()                          # gloo knows nothing of the GPU: finish the stores first
+            work = dist.all_reduce(token, async_op=True)          # after every rank's stores of this group (stream order)
+        elif rehearse:
             work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
         else:
             work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
         pending.append((work, slot, group["fill"]))              # overlaps with the renders of the next group
+        group["last_slot"] = slot
         group["slot"], group["fill"] = slot ^ 1, 0
 
     def step(k):
@@ -250,18 +354,31 @@ def main():
 
     # one more (untimed) step; EVERY rank checks the frame it reassembled against the rows the reference itself
     # rendered (tests/golden, fixtures - not the oracle), and the worst rank is reported
+    fence()
     frames.zero_()
-    torch.cuda.synchronize()
+    if p2p and lib.rt_memset_device(dev_index, my_buf, 0, 2 * every * frame_bytes) != 0:
+        raise SystemExit("bench.py: rt_memset_device: " + lib.rt_last_error().decode())
+    fence()                                                        # nobody stores into a buffer that is still being cleared
     for k in range(every):                                         # one whole group, so every frame slot is rewritten
         step(k)
     drain()
-    torch.cuda.synchronize()
+    fence()
+    import numpy as np
     import oracle_util as ou
+
+    def reassembled(j):
+        if not p2p:
+            return frames[j].cpu().numpy()
+        host = np.empty((h, w, 4), dtype=np.uint8)
+        if lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf + (group["last_slot"] * every + j) * frame_bytes, frame_bytes) != 0:
+            raise SystemExit("bench.py: rt_copy_to_host: " + lib.rt_last_error().decode())
+        return host
+
     max_lsb = None
     for f in ou.manifest()["frames"]:
         if f["scene"] == args.scene and (f["w"], f["h"]) == (w, h) and f["rows"]:
             for j in range(every):
-                got = frames[j][f["rows"]].cpu().numpy().reshape(-1)
+                got = np.ascontiguousarray(reassembled(j)[f["rows"]]).reshape(-1)
                 max_lsb = max(max_lsb or 0, ou.max_lsb(got, ou.golden_frame(f))[0])
     if world > 1 and max_lsb is not None:
         t = torch.tensor([int(max_lsb)], dtype=torch.int64, device="cpu" if rehearse else dev)
@@ -287,6 +404,10 @@ def main():
                 traffic = tj[key]["hbm_bytes_per_launch"]
         if not multi:
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
+        elif p2p:
+            how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
+                   "frame buffer of the rank that owns each frame (peer-mapped over xGMI, RGBA8, rows in place): no data collective, no "
+                   "de-interleave; one all_reduce per %d steps is the barrier" % (world, TILE_ROWS, world, every))
         else:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
                    "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
@@ -311,7 +432,12 @@ def main():
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
                           "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
         }
-        if multi:
+        if p2p_note:
+            out["config"]["plan_note"] = p2p_note
+        if multi and p2p:
+            out["exchange"] = {"plan": "peer stores (rt_render_scatter_device through IPC-mapped frame buffers)", "collective": "all_reduce of one int per group (barrier)",
+                               "bytes_stored_remotely_per_rank_per_step": (world - 1) * plan.pixels_of(rank) * 4, "steps_per_barrier": every}
+        elif multi:
             out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
                                "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
                                "steps_per_collective": every}
@@ -323,6 +449,13 @@ def main():
         print(json.dumps(out), flush=True)
 
     renderer.close()
+    if p2p:
+        fence()
+        for g in range(world):
+            if g != rank:
+                lib.rt_ipc_close(dev_index, peer_buf[g])
+        fence()
+        lib.rt_free_device(dev_index, my_buf)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -744,6 +744,15 @@ extern "C" int rt_copy_to_host(int device, void *dst, const void *src, size_t by
   return RT_OK;
 }
 
+extern "C" int rt_memset_device(int device, void *dst, int value, size_t bytes) {
+  if (!dst) return fail(RT_ERR_INVALID, "rt_memset_device: NULL destination");
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  HIP_TRY(hipMemset(dst, value, bytes));
+  HIP_TRY(hipDeviceSynchronize());
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------ de-interleave
 // src: for rank g, its tiles (g, g+R, g+2R, ...) stored contiguously, ranks `rank_stride` bytes apart.
 // dst: the frame in row order.  One workgroup row per frame row (grid y), so the tile/rank arithmetic is

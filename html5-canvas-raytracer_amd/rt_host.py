@@ -157,6 +157,7 @@ ABI = {
     "rt_copy_to_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rt_deinterleave_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint64, C.c_void_p]),
+    "rt_memset_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_size_t]),
     "rt_render_scatter_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p,
                                            C.c_uint32, C.POINTER(RtStats)]),
     "rt_ipc_export": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),

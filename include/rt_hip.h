@@ -210,6 +210,7 @@ void rt_free_pinned(void *p);
 void *rt_alloc_device(int device, size_t bytes);
 void rt_free_device(int device, void *p);
 int rt_copy_to_host(int device, void *dst_host, const void *src_device, size_t bytes);
+int rt_memset_device(int device, void *dst_device, int byte_value, size_t bytes);   /* synchronous */
 
 /* De-interleave a gathered frame: src holds, for rank g in [0,n_ranks), that rank's tiles
  * (g, g+n_ranks, ...) contiguously with `rank_stride_bytes` between ranks; dst receives the
