@@ -140,6 +140,25 @@ def test_ragged_frame_sizes(lib, w, h):
     assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1
 
 
+@pytest.mark.parametrize("scene,w,h", [("h8", 65536, 8), ("h8", 8, 65536), ("lcg64", 32768, 4), ("default14", 4, 32768)])
+def test_maximum_frame_extents(lib, scene, w, h):
+    """The largest width and height the ABI accepts (65536), as thin frames so that the oracle stays cheap: the pixel
+    index, the tile / row-block split of grid y (8192 and, with supersampling, 2 rows per workgroup) and the cull
+    rectangles at extreme aspect ratios."""
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1
+    r = rt_host.Renderer(blob, 0, lib)
+    d = lib.rt_alloc_device(0, 4096)
+    try:
+        with pytest.raises(RuntimeError):
+            r.render_tiles(65537, 8, d, rt_host.RtTiles(8, 0, 1, 1))
+        with pytest.raises(RuntimeError):
+            r.render_tiles(8, 65537, d, rt_host.RtTiles(8, 0, 1, 1))
+    finally:
+        lib.rt_free_device(0, d)
+        r.close()
+
+
 def test_depth_zero_is_black_and_no_lights_is_ambient_only(lib):
     s = rt_host.load_scene("h8")
     s["segs"] = 0
