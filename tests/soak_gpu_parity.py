@@ -40,7 +40,7 @@ def look_at(org, tgt, up):
     return {"origin": org.tolist(), "axisX": unit(x).tolist(), "axisY": unit(y).tolist(), "axisZ": unit(z).tolist()}
 
 
-def draw_scene(seed, degenerate=False):
+def draw_scene(seed, degenerate=False, many=False):
     rng = random.Random(seed)
     base = rt_host.load_scene("default14_stars")          # carries the two PNG textures and the checker texture
     ground_sky = [o for o in base["objects"] if o["r2"] >= 250000.0]
@@ -51,7 +51,7 @@ def draw_scene(seed, degenerate=False):
             sky = [o for o in objs if o["r2"] > 1e6][0]
             sky["mtl"] = dict(sky["mtl"], sampler={"kind": 0})
     refract = rng.random() < 0.4
-    n = rng.choice([1, 2, 3, 5, 8, 12, 13, 14, 20, 33, 64, 65, 90])
+    n = rng.choice([25, 33, 48, 64, 65, 90, 128, 200]) if many else rng.choice([1, 2, 3, 5, 8, 12, 13, 14, 20, 33, 64, 65, 90])
     spread = 2.0 + 0.12 * n
     while len(objs) < n:
         r = rng.choice([rng.uniform(0.05, 0.4), rng.uniform(0.3, 1.5), rng.uniform(1.0, 4.0)])
@@ -100,6 +100,9 @@ def draw_scene(seed, degenerate=False):
              fovDeg=rng.choice([60.0, 60.0, 20.0, 35.0, 90.0, 150.0]), light_intensity=rng.choice([50.0, 30.0, 5.0]))
     w = rng.choice([32, 64, 96, 100, 131, 160, 33])
     h = rng.choice([24, 48, 64, 64, 77, 90, 90, 9])
+    if many:                                                # the shadow grids and the bounce table at work: depth >= 2, larger frames
+        s["segs"] = rng.choice([2, 3, 5, 8])
+        w, h = rng.choice([(160, 90), (192, 128), (256, 144), (131, 77)])
     return s, w, h
 
 
@@ -108,6 +111,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=300)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--many-spheres", action="store_true", help="25..200 spheres, depth >= 2, larger frames: the shadow-grid / bounce-table variants")
     ap.add_argument("--degenerate-lights", action="store_true", help="also place lights at the centres of the ground/sky spheres ([0,0,0] is ON the ground sphere)")
     args = ap.parse_args()
     lib = rt_host.load_library()
@@ -117,7 +121,7 @@ def main():
     tot = {k: {"channels": 0, "off_by_one": 0, "flipped_pixels": 0, "worst": 0, "scenes_with_flips": []} for k in ("fma", "strict")}
     pixels = 0
     for seed in range(args.first, args.first + args.seeds):
-        scene, w, h = draw_scene(seed, args.degenerate_lights)
+        scene, w, h = draw_scene(seed, args.degenerate_lights, args.many_spheres)
         blob = rt_host.flatten_scene(scene)
         want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h * w, 4).astype(np.int16)
         pixels += w * h
