@@ -83,8 +83,8 @@ def cpu_baseline(scene_name, w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=2000)     # 0.25 s timed at N=1: start-up and the final sync (~0.8 ms) no longer show
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="h8")
     ap.add_argument("--width", type=int, default=FRAME_W)
     ap.add_argument("--height", type=int, default=FRAME_H)
@@ -342,14 +342,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- dominant kernel: average launch duration, HIP events on the launch stream ----
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 20))]
-    for a, b in evs:
-        a.record()
+    # ---- dominant kernel: average launch duration, HIP events on the launch stream.  At N=1 the timed region IS a train of
+    #      these launches on this stream, so two events around the region give the average over every launch of it (what
+    #      rocprofv3's per-kernel average of the same command shows); at N>1 the region also waits for slots, so the kernel is
+    #      timed on a train of its own right after ----
+    fence()
+    n_train = args.steps if not multi else min(args.steps, 200)
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(min(10, n_train)):
         render_step(0)
-        b.record()
+    ev_a.record()
+    for _ in range(n_train):
+        render_step(0)
+    ev_b.record()
     torch.cuda.synchronize()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    kernel_ms = ev_a.elapsed_time(ev_b) / n_train
     launch_pixels = w * h if not multi else world * plan.pixels_of(rank)
 
     # one more (untimed) step; EVERY rank checks the frame it reassembled against the rows the reference itself

@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 SUM=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline"   # the default command (200 steps, 10 warm-up), minus the CPU leg
+BENCH="python3 $REPO/bench.py --no-cpu-baseline"   # the default command (2000 steps, 20 warm-up), minus the CPU leg
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?" >> "$OUT/trace.log"
