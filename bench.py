@@ -26,7 +26,7 @@ step is one frame's worth of pixels at every N (weak scaling).  Two plans put th
     row is whole 128-byte lines written by one workgroup.  No data collective, no send/recv buffers, no RCCL copy
     kernels, no de-interleave: one all_reduce of one int per group of steps is the barrier.  Measured on ONE GPU
     with one rank (RT_BENCH_FORCE_EXCHANGE=1): the all-to-all plan's own machinery costs 13 % (59 vs 68.7
-    Gpixel/s), the peer-store plan 3 % (66.6).  It ships the alpha byte, so it needs 4.1 MB per link per step at
+    Gpixel/s), the peer-store plan 5 % (65.2; its workgroups transpose their tile through LDS to store whole lines).  It ships the alpha byte, so it needs 4.1 MB per link per step at
     N=8 (33 GB/s, half a link) but would be link-bound below N=6.  Set-up and a one-step PRE-FLIGHT (every rank
     checks the frame it owns against the reference's rows) run first; any failure on any rank makes all ranks
     fall back to the all-to-all plan, and the JSON says so.  RT_BENCH_P2P=1/0 forces a plan.

@@ -622,7 +622,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   // RT_LDS_PAD (bytes): occupancy experiments only — extra dynamic LDS per workgroup caps the workgroups per CU
   static const unsigned lds_pad = getenv("RT_LDS_PAD") ? (unsigned)atoi(getenv("RT_LDS_PAD")) : 0u;
   const int err = ((flags & RT_FLAG_STRICT_FP) ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2,
-      s->lds_bytes + lds_pad + (!(flags & RT_FLAG_STRICT_FP) ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u : 0u),   // + the product kernels' fold state
+      s->lds_bytes + lds_pad + (!(flags & RT_FLAG_STRICT_FP) ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
+                                                             : RT_WG_THREADS * 8u),                           //   (strict: one slot, the scatter store's tile)
       stream);
   if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
   if (stats) {

@@ -923,7 +923,22 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     packed += __shfl_xor(packed, 2);
     rgbw = (((packed & 1023u) + 2u) >> 2) | ((((packed >> 10) & 1023u) + 2u) >> 2 << 8) | ((((packed >> 20) & 1023u) + 2u) >> 2 << 16);
   }
-  if (!L.rgb24) {                                      // wave-uniform
+  if (!L.rgb24 && L.scatter && !SS2) {                 // workgroup-uniform
+    // Peer stores want whole lines: a wave's 8x8 block is eight 32-byte pieces, one per row, and memory on the far side
+    // of an xGMI link has no L2 of ours in front of it to merge them.  So the workgroup transposes its 32x8 tile through
+    // LDS - every lane parks its pixel in its own fold-state slot 0, dead by now - and each wave then stores two whole
+    // 128-byte rows of the tile.
+    uint32_t *tile = (uint32_t *)(lds_raw + image_words);
+    tile[2u * tid2] = rgbw;
+    __syncthreads();
+    const uint32_t xr = tid2 & 31u, rr = tid2 >> 5;     // this work-item's pixel of the tile in row-major order
+    const uint32_t v = tile[2u * (((xr >> 3) << 6) + (rr << 3) + (xr & 7u))];
+    const uint32_t lane2 = tid2 & 63u;
+    const uint32_t px2 = P1.px - ((tid2 >> 6) * 8u + (lane2 & 7u)) + xr;
+    const uint32_t dr = rr - (lane2 >> 3);              // row of the tile: difference in wrap-around arithmetic
+    const uint32_t trow2 = P1.trow + dr, frow2 = P1.frow + dr;
+    if (px2 < L.w && trow2 < L.tile_rows && frow2 < L.h) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
+  } else if (!L.rgb24) {                               // wave-uniform
     if (valid && P1.sub == 0u) out[(size_t)orow * L.w + P1.px] = rgbw | 0xff000000u;
   } else {
     // RT_FLAG_RGB24: the 8 pixels a wave holds of one row are 24 bytes = 6 words.  Word j of the group takes its bytes
