@@ -617,7 +617,12 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
 
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // timing events of a stats call; released on every way out of this function
+  struct event_pair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~event_pair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
   // RT_LDS_PAD (bytes): occupancy experiments only — extra dynamic LDS per workgroup caps the workgroups per CU
   static const unsigned lds_pad = getenv("RT_LDS_PAD") ? (unsigned)atoi(getenv("RT_LDS_PAD")) : 0u;
@@ -631,7 +636,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     memset(stats, 0, sizeof *stats);
     stats->kernel_ms = ms;
     uint64_t px = 0;
