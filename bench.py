@@ -420,6 +420,25 @@ def main():
                    "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
                    "collective, which overlaps the renders of the next %d steps"
                    % (world, TILE_ROWS, world, "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
+        # the store roofline as this box delivers it (quote a measured fill next to the nominal peak): a 2 GiB
+        # torch fill, best of 5, on the launch stream
+        fill_gbs = None
+        if not multi:
+            try:
+                big = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+                best = None
+                for _ in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    big.fill_(7)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    best = ms if best is None else min(best, ms)
+                fill_gbs = round((2 << 30) / (best * 1e-3) / 1e9, 1)
+                del big
+            except Exception:      # noqa: BLE001  (a small box: the nominal peak stands alone)
+                fill_gbs = None
         out = {
             "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -434,6 +453,7 @@ def main():
             "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                         "measured_fill_GBs": fill_gbs, "frac_of_measured_fill": (round(achieved / fill_gbs, 6) if fill_gbs else None),
                          "note": "%d B per output pixel (one %s store); the path is FP64-VALU bound, see fp64_valu" % (channels, "RGBA8" if channels == 4 else "RGB24")},
             "fp64_valu": {"flop_per_pixel_model": round(flops_pp, 1), "achieved": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12, 3),
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
