@@ -887,7 +887,25 @@ int ensure_frame(device_state &D, size_t bytes) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------ render(width,height,scene)
+namespace {
+int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats,
+                   uint32_t want_bands, rt_band_callback on_band, void *user);
+}  // namespace
+
 extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats) {
+  return render_to_host(blob, bytes, w, h, out_rgba, flags, stats, 0u, nullptr, nullptr);
+}
+
+extern "C" int rt_render_progressive(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t n_bands,
+                                     rt_band_callback on_band, void *user, uint32_t flags, rt_stats *stats) {
+  if (n_bands == 0 || n_bands > 64u) return fail(RT_ERR_INVALID, "n_bands %u not in 1..64", n_bands);
+  if (!on_band) return fail(RT_ERR_INVALID, "on_band is NULL");
+  return render_to_host(blob, bytes, w, h, out_rgba, flags, stats, n_bands, on_band, user);
+}
+
+namespace {
+int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats,
+                   uint32_t want_bands, rt_band_callback on_band, void *user) {
   if (!out_rgba) return fail(RT_ERR_INVALID, "out_rgba is NULL");
   if (flags & RT_FLAG_RGB24) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 applies to the device entry points only; rt_render returns ImageData.data (RGBA8)");
   if (!G.inited) return fail(RT_ERR_STATE, "rt_init has not been called");
@@ -911,9 +929,11 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
       if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy stream: %s", hipGetErrorString(e));
     }
     const bool count = (flags & RT_FLAG_COUNT) != 0;
-    const uint32_t n_bands = (count || frame_bytes < (8u << 20)) ? 1u : 4u;      // counters come from one instrumented launch
+    // counters come from one instrumented launch; a caller that asked for bands (rt_render_progressive) gets that many
+    const uint32_t n_bands = count ? 1u : (want_bands ? want_bands : (frame_bytes < (8u << 20) ? 1u : 4u));
     const uint32_t band_rows = ((h + n_bands - 1) / n_bands + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, band_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> band_done(n_bands, nullptr), copy_done(n_bands, nullptr);
     if (!rc) {
       rt_stats st;
       memset(&st, 0, sizeof st);
@@ -924,6 +944,7 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
           hipError_t e = hipMemcpyAsync(out_rgba, D.d_frame, frame_bytes, hipMemcpyDeviceToHost, D.stream);
           if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
           if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+          if (!rc && on_band) on_band(user, 0u, h);
         }
       } else {
         hipError_t e = hipEventCreate(&ev0);
@@ -941,14 +962,25 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
           if (e == hipSuccess) e = hipEventRecord(band_done[b], D.stream);
           if (e == hipSuccess) e = hipStreamWaitEvent(D.copy_stream, band_done[b], 0);
           if (e == hipSuccess) e = hipMemcpyAsync(out_rgba + (size_t)r0 * w * 4u, d_band, (size_t)rows * w * 4u, hipMemcpyDeviceToHost, D.copy_stream);
+          if (e == hipSuccess && on_band) e = hipEventCreateWithFlags(&copy_done[b], hipEventDisableTiming);
+          if (e == hipSuccess && on_band) e = hipEventRecord(copy_done[b], D.copy_stream);
         }
         if (e == hipSuccess && !rc) e = hipEventRecord(ev1, D.stream);
+        // progressive delivery: every band is announced as soon as its rows are in the caller's buffer, while the
+        // later bands are still rendering or on the PCIe link (the reference shows its frame row by row, main.js:201)
+        for (uint32_t b = 0; on_band && b < n_bands && e == hipSuccess && !rc; b++) {
+          if (!copy_done[b]) break;
+          e = hipEventSynchronize(copy_done[b]);
+          const uint32_t r0 = b * band_rows;
+          if (e == hipSuccess) on_band(user, r0, (r0 + band_rows <= h) ? band_rows : h - r0);
+        }
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.stream);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.copy_stream);
         if (e == hipSuccess && !rc) { float ms = 0.f; e = hipEventElapsedTime(&ms, ev0, ev1); st.kernel_ms = ms; }
         if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "banded render/copy-out: %s", hipGetErrorString(e));
         st.pixels = (uint64_t)w * h;
         for (hipEvent_t ev : band_done) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : copy_done) if (ev) (void)hipEventDestroy(ev);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
       }
@@ -1030,11 +1062,13 @@ extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h,
     }
     if (rc) return rc;
     agg.pixels = (uint64_t)w * h;
+    if (on_band) on_band(user, 0u, h);           // several GPUs: the frame arrives whole
   }
   agg.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = agg;
   return RT_OK;
 }
+}  // namespace
 
 extern "C" void rt_shutdown(void) {
   {

@@ -42,6 +42,22 @@ function renderAsync(width, height, sceneObj, opts) {
   return native().renderAsync(flattenScene(sceneObj), width, height, flagsOf(opts)).then((r) => { r.data.stats = r.stats; return r.data; });
 }
 
+// Progressive variant: the reference shows its frame row by row (one spanish(y) per macrotask, main.js:183-201); here
+// the frame is rendered as `bands` row bands (default 8, at most 64) and onBand({firstRow, rows, data}) fires on the main
+// thread as each band lands in the frame buffer - `data` is the view of just those rows, `frame` the whole buffer that
+// is being filled (usable with putImageData(..., dirtyY) while it fills).  Resolves to the full frame.
+function renderProgressive(width, height, sceneObj, opts) {
+  try { if (!inited) init(opts && opts.maxDevices); } catch (e) { return Promise.reject(e); }
+  const bands = (opts && opts.bands) || 8;
+  const onBand = (opts && opts.onBand) || (() => {});
+  let r;
+  try {
+    r = native().renderProgressive(flattenScene(sceneObj), width, height, flagsOf(opts), bands,
+      (firstRow, rows) => onBand({firstRow, rows, frame: r.data, data: r.data.subarray(firstRow * width * 4, (firstRow + rows) * width * 4)}));
+  } catch (e) { return Promise.reject(e); }
+  return r.promise.then((stats) => { r.data.stats = stats; return r.data; });
+}
+
 function shutdown() { if (addon) addon.shutdown(); inited = false; }
 
-module.exports = Object.assign({render, renderAsync, init, shutdown, flattenScene, scenes, native}, scene);
+module.exports = Object.assign({render, renderAsync, renderProgressive, init, shutdown, flattenScene, scenes, native}, scene);

@@ -8,6 +8,9 @@
 //   GET /                               the page
 //   GET /frame?scene=h8&w=1280&h=720    raw RGBA8, w*h*4 bytes (ImageData.data layout);
 //                                       headers X-Width, X-Height, X-Kernel-Ms, X-Total-Ms
+//   GET /frame?...&progressive=8        the same bytes as a CHUNKED response, one chunk per row band as it leaves the
+//                                       GPU (renderProgressive): the page paints top to bottom like the reference's
+//                                       scanline loop (main.js:183-201)
 //   GET /scenes                         JSON list of scene names
 // Errors (no GPU, bad scene, bad size) are JSON with status 4xx/5xx; never a CPU-rendered frame.
 //
@@ -32,12 +35,22 @@ const PAGE = `<!DOCTYPE html>
   const ctx = canvas.getContext('2d');
   const scene = new URLSearchParams(location.search).get('scene') || 'default14_stars';
   const t0 = Date.now();
-  const r = await fetch('/frame?scene=' + scene + '&w=' + canvas.width + '&h=' + canvas.height);
+  const w = canvas.width, h = canvas.height;
+  const r = await fetch('/frame?scene=' + scene + '&w=' + w + '&h=' + h + '&progressive=8');
   if (!r.ok) { ctx.fillStyle = '#f44'; ctx.font = '16px monospace'; ctx.fillText((await r.json()).error, 8, 24); return; }
-  const data = new Uint8ClampedArray(await r.arrayBuffer());
-  ctx.putImageData(new ImageData(data, canvas.width, canvas.height), 0, 0);
+  // paint whole rows as the chunks arrive (the reference paints one scanline per macrotask)
+  const data = new Uint8ClampedArray(w * h * 4);
+  const reader = r.body.getReader();
+  let got = 0, painted = 0;
+  for (;;) {
+    const {done, value} = await reader.read();
+    if (done) break;
+    data.set(value, got); got += value.length;
+    const rows = Math.floor(got / (w * 4));
+    if (rows > painted) { ctx.putImageData(new ImageData(data.subarray(painted * w * 4, rows * w * 4), w, rows - painted), 0, painted); painted = rows; }
+  }
   ctx.font = '16px monospace'; ctx.textBaseline = 'top'; ctx.fillStyle = '#ffffff';
-  ctx.fillText('MI355X kernel ' + r.headers.get('X-Kernel-Ms') + 'ms, round trip ' + (Date.now() - t0) + 'ms', 0, 0);
+  ctx.fillText('MI355X, round trip ' + (Date.now() - t0) + 'ms', 0, 0);
 })();
 </script></body></html>`;
 
@@ -78,6 +91,23 @@ function createServer(opts) {
       if (!(w > 0 && h > 0 && w <= 65536 && h <= 65536 && w * h <= maxPixels)) return sendJSON(res, 400, {error: 'w and h must be positive integers within the frame limit'});
       let scene;
       try { scene = loadNamedScene(String(u.query.scene || 'default14_stars')); } catch (e) { return sendJSON(res, e.status || 500, {error: e.message}); }
+      const bands = parseInt(u.query.progressive || '0', 10);
+      if (bands > 0) {
+        // chunked: each band is written as soon as it is in the pinned frame; headers cannot carry the timings any more
+        // (they are known at the end), so they travel as HTTP trailers
+        let started = false;
+        return RT.renderProgressive(w, h, scene, {bands: Math.min(bands, 64), onBand: (b) => {
+          if (!started) {
+            res.writeHead(200, {'Content-Type': 'application/octet-stream', 'X-Width': w, 'X-Height': h, 'Cache-Control': 'no-store',
+              'Trailer': 'X-Kernel-Ms, X-Total-Ms'});
+            started = true;
+          }
+          res.write(Buffer.from(b.data.buffer, b.data.byteOffset, b.data.length));
+        }}).then((data) => {
+          res.addTrailers({'X-Kernel-Ms': data.stats.kernel_ms.toFixed(3), 'X-Total-Ms': data.stats.total_ms.toFixed(3)});
+          res.end();
+        }).catch((e) => { if (started) res.destroy(e); else sendJSON(res, 503, {error: e.message}); });
+      }
       // renderAsync keeps the event loop free while the GPU works; the reply streams the pinned frame
       return RT.renderAsync(w, h, scene).then((data) => {
         res.writeHead(200, {'Content-Type': 'application/octet-stream', 'Content-Length': data.length, 'X-Width': w, 'X-Height': h,

@@ -6,6 +6,8 @@
 //
 // Exports:  init(maxDevices) -> deviceCount      render(blob, w, h, flags) -> {data, width, height, stats}
 //           renderAsync(blob, w, h, flags) -> Promise of the same        shutdown()      abiVersion()
+//           renderProgressive(blob, w, h, flags, bands, onBand(firstRow, nRows)) -> {data, promise}: `data` is the frame
+//           being filled; onBand fires on the main thread as each row band lands in it; the promise resolves to the stats
 // Every failure of the library becomes a thrown JS Error carrying rt_last_error().
 //
 // Build: g++ -shared -fPIC -I/usr/include/node rt_napi.cc -L../csrc -lrt_hip  (napi/Makefile; no node-gyp).
@@ -170,6 +172,98 @@ napi_value RenderAsync(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+// ---- progressive delivery: the frame buffer exists from the start (the page can keep a view of it), bands are announced
+//      from the worker thread through a thread-safe function, the promise resolves when the frame is whole ----
+struct prog_args : args {
+  uint32_t bands = 4;
+  napi_threadsafe_function tsfn = nullptr;
+};
+struct band_note { uint32_t row0, rows; };
+
+void prog_call_js(napi_env env, napi_value js_cb, void *, void *data) {
+  band_note *b = (band_note *)data;
+  if (env && js_cb) {
+    napi_value undef, argv[2];
+    napi_get_undefined(env, &undef);
+    napi_create_uint32(env, b->row0, &argv[0]);
+    napi_create_uint32(env, b->rows, &argv[1]);
+    napi_call_function(env, undef, js_cb, 2, argv, nullptr);
+  }
+  delete b;
+}
+
+void prog_on_band(void *user, uint32_t row0, uint32_t rows) {
+  prog_args *a = (prog_args *)user;
+  napi_call_threadsafe_function(a->tsfn, new band_note{row0, rows}, napi_tsfn_blocking);
+}
+
+void prog_exec(napi_env, void *p) {
+  prog_args *a = (prog_args *)p;
+  a->rc = rt_render_progressive(a->blob, a->bytes, a->w, a->h, a->out, a->bands, prog_on_band, a, a->flags, &a->st);
+  if (a->rc != RT_OK) a->err = rt_last_error();
+}
+
+// The band notes travel through the thread-safe function's queue; the async work's completion callback may overtake the
+// last of them.  So the work's completion only RELEASES the function, and the promise is settled in the function's
+// finalizer, which runs on the main thread after the queue has drained: every onBand has fired before the promise resolves.
+void prog_done(napi_env env, napi_status, void *p) {
+  prog_args *a = (prog_args *)p;
+  napi_delete_async_work(env, a->work);
+  napi_release_threadsafe_function(a->tsfn, napi_tsfn_release);
+}
+
+void prog_finalize(napi_env env, void *data, void *) {
+  prog_args *a = (prog_args *)data;
+  if (a->rc == RT_OK) {
+    napi_value stats, v;
+    napi_create_object(env, &stats);
+    napi_create_double(env, a->st.kernel_ms, &v); napi_set_named_property(env, stats, "kernel_ms", v);
+    napi_create_double(env, a->st.total_ms, &v); napi_set_named_property(env, stats, "total_ms", v);
+    napi_create_double(env, (double)a->st.pixels, &v); napi_set_named_property(env, stats, "pixels", v);
+    napi_resolve_deferred(env, a->deferred, stats);
+  } else {
+    napi_value msg, err;
+    std::string m = "rt_render_progressive failed (" + std::to_string(a->rc) + "): " + a->err;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &err);
+    napi_reject_deferred(env, a->deferred, err);
+  }
+  if (a->owned) free(a->blob);
+  delete a;
+}
+
+napi_value RenderProgressive(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  napi_valuetype t = napi_undefined;
+  if (argc >= 6) napi_typeof(env, argv[5], &t);
+  if (argc < 6 || t != napi_function) { napi_throw_type_error(env, nullptr, "renderProgressive(blob, width, height, flags, bands, onBand)"); return nullptr; }
+  prog_args *a = new prog_args();
+  if (!parse(env, info, a, true)) { if (a->owned) free(a->blob); delete a; return nullptr; }
+  napi_get_value_uint32(env, argv[4], &a->bands);
+  const size_t n = (size_t)a->w * a->h * 4u;
+  a->out = (uint8_t *)rt_alloc_pinned(n);
+  if (!a->out) { if (a->owned) free(a->blob); delete a; return throw_rt(env, "rt_alloc_pinned", RT_ERR_NOMEM); }
+  napi_value ab, ta, res, promise, name;
+  // from here on the pinned frame belongs to the ArrayBuffer (freed by its finalizer, whatever happens to the render)
+  if (napi_create_external_arraybuffer(env, a->out, n, free_pinned, nullptr, &ab) != napi_ok) {
+    rt_free_pinned(a->out); if (a->owned) free(a->blob); delete a;
+    napi_throw_error(env, nullptr, "napi_create_external_arraybuffer failed");
+    return nullptr;
+  }
+  NAPI_TRY(napi_create_typedarray(env, napi_uint8_clamped_array, n, ab, 0, &ta));
+  NAPI_TRY(napi_create_promise(env, &a->deferred, &promise));
+  napi_create_string_utf8(env, "rt_render_progressive", NAPI_AUTO_LENGTH, &name);
+  NAPI_TRY(napi_create_threadsafe_function(env, argv[5], nullptr, name, 0, 1, a, prog_finalize, nullptr, prog_call_js, &a->tsfn));
+  NAPI_TRY(napi_create_async_work(env, nullptr, name, prog_exec, prog_done, a, &a->work));
+  NAPI_TRY(napi_queue_async_work(env, a->work));
+  NAPI_TRY(napi_create_object(env, &res));
+  napi_set_named_property(env, res, "data", ta);
+  napi_set_named_property(env, res, "promise", promise);
+  return res;
+}
+
 napi_value Shutdown(napi_env, napi_callback_info) { rt_shutdown(); return nullptr; }
 
 napi_value AbiVersion(napi_env env, napi_callback_info) {
@@ -198,6 +292,7 @@ napi_value Module(napi_env env, napi_value exports) {
       {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"render", nullptr, Render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"renderAsync", nullptr, RenderAsync, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"renderProgressive", nullptr, RenderProgressive, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"validate", nullptr, Validate, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"shutdown", nullptr, Shutdown, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

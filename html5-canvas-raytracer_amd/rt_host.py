@@ -150,6 +150,8 @@ ABI = {
     "rt_render_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
     "rt_render": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
+    "rt_render_progressive": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                        C.POINTER(RtStats)]),
     "rt_alloc_pinned": (C.c_void_p, [C.c_size_t]),
     "rt_free_pinned": (None, [C.c_void_p]),
     "rt_alloc_device": (C.c_void_p, [C.c_int, C.c_size_t]),

@@ -201,6 +201,15 @@ int rt_ipc_close(int device, void *d_ptr);
 int rt_render(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h,
               uint8_t *out_rgba, uint32_t flags, rt_stats *stats);
 
+/* The same, delivered progressively: the frame is rendered as n_bands (1..64) row bands and on_band(user, first_row,
+ * n_rows) is called - on the calling thread, in row order - as soon as a band's rows are in out_rgba, while later bands
+ * are still rendering or crossing PCIe.  This is the reference's row-by-row display (spanish(y) per macrotask,
+ * main.js:183-201) with bands for rows.  With several GPUs in use the frame arrives whole (one call).  on_band runs
+ * inside the library's render lock: it must not call rt_render / rt_render_progressive itself. */
+typedef void (*rt_band_callback)(void *user, uint32_t first_row, uint32_t n_rows);
+int rt_render_progressive(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, uint8_t *out_rgba,
+                          uint32_t n_bands, rt_band_callback on_band, void *user, uint32_t flags, rt_stats *stats);
+
 /* Pinned host framebuffers (the ImageData buffer of main.js:83 becomes one of these). */
 void *rt_alloc_pinned(size_t bytes);
 void rt_free_pinned(void *p);

@@ -27,6 +27,22 @@ function maxDiff(a, b) { let m = 0; if (a.length !== b.length) return 999; for (
   out.constructed = maxDiff(rt.render(h8.w, h8.h, rt.scenes.h8(tex, 3)), fs.readFileSync(path.join(GOLD, h8.file)));
   const a = await rt.renderAsync(h8.w, h8.h, load('h8'));
   out.async = maxDiff(a, fs.readFileSync(path.join(GOLD, h8.file)));
+  // progressive delivery: bands arrive in row order, each band's view holds the reference's rows at the moment it is
+  // announced, the bands cover the frame exactly, and the resolved frame is the whole frame
+  {
+    const gold = fs.readFileSync(path.join(GOLD, h8.file));
+    const seen = [];
+    let worst = 0;
+    const frame = await rt.renderProgressive(h8.w, h8.h, load('h8'), {bands: 5, onBand: (b) => {
+      seen.push([b.firstRow, b.rows]);
+      worst = Math.max(worst, maxDiff(b.data, gold.subarray(b.firstRow * h8.w * 4, (b.firstRow + b.rows) * h8.w * 4)));
+    }});
+    out.progressive = {bands: seen, bandDiff: worst, frameDiff: maxDiff(frame, gold), kernel_ms: frame.stats.kernel_ms};
+    // a large frame (really banded: > 8 MB) - only structure is checked here
+    const big = [];
+    const f2 = await rt.renderProgressive(2048, 1100, load('h8'), {bands: 8, onBand: (b) => big.push([b.firstRow, b.rows])});
+    out.progressiveBig = {bands: big, length: f2.length, same: maxDiff(f2, rt.render(2048, 1100, load('h8')))};
+  }
   const c = rt.render(h8.w, h8.h, load('h8'), {count: true});
   out.counted = {rays: c.stats.rays, pixels: c.stats.pixels};
   let threw = '';

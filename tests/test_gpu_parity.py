@@ -361,6 +361,44 @@ def test_bounce_table_is_exact(lib, seed, n, refract, segs):
     assert r.stdout.strip().splitlines()[-1] == hashlib.sha256(gpu_frame(lib, blob, 192, 128)).hexdigest()
 
 
+def test_progressive_render_announces_bands_in_order(lib):
+    """rt_render_progressive (the reference's row-by-row display): on_band fires once per band, in row order,
+    gap-free, and when it fires the band's rows in the caller's buffer already are the final rows; the finished frame is
+    the frame rt_render gives."""
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    for w, h, bands in ((2048, 1100, 7), (320, 200, 3), (64, 10, 64)):
+        n = w * h * 4
+        want, _ = rt_host.render(w, h, blob, lib=lib)
+        out = lib.rt_alloc_pinned(n)
+        C.memset(out, 0, n)
+        seen = []
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
+
+        def on_band(_user, row0, rows):
+            got = C.string_at(out + row0 * w * 4, rows * w * 4)
+            seen.append((row0, rows, got == want[row0 * w * 4:(row0 + rows) * w * 4]))
+
+        cb = CB(on_band)
+        try:
+            st = rt_host.RtStats()
+            buf = C.create_string_buffer(blob, len(blob))
+            rc = lib.rt_render_progressive(buf, len(blob), w, h, C.c_void_p(out), bands, C.cast(cb, C.c_void_p), None, 0, C.byref(st))
+            assert rc == 0, lib.rt_last_error()
+            assert C.string_at(out, n) == want
+        finally:
+            lib.rt_free_pinned(out)
+        assert all(ok for _, _, ok in seen), (w, h, seen)
+        assert [r0 for r0, _, _ in seen] == [sum(r for _, r, _ in seen[:i]) for i in range(len(seen))]
+        assert sum(r for _, r, _ in seen) == h and 1 <= len(seen) <= bands
+    buf = C.create_string_buffer(blob, len(blob))
+    out = lib.rt_alloc_pinned(64)
+    try:
+        assert lib.rt_render_progressive(buf, len(blob), 4, 4, C.c_void_p(out), 0, None, None, 0, None) == -1
+        assert lib.rt_render_progressive(buf, len(blob), 4, 4, C.c_void_p(out), 4, None, None, 0, None) == -1
+    finally:
+        lib.rt_free_pinned(out)
+
+
 def test_device_entry_points_from_concurrent_threads(lib):
     """include/rt_hip.h: the device entry points may be called from several threads at once.  Four threads, each with its
     own scene, renderer and output buffer (ctypes releases the GIL during the calls), render repeatedly; every frame must

@@ -25,7 +25,7 @@ try { rt.render(16, 16, sc); out.err = 'rendered'; } catch (e) { out.err = e.mes
 console.log(JSON.stringify(out));
 """ % (PKG, PKG, PKG, PKG)
     out = json.loads(subprocess.check_output([ou.node_path(), "-e", js], text=True))
-    assert out["exports"] == ["abiVersion", "init", "render", "renderAsync", "shutdown", "validate"]
+    assert out["exports"] == ["abiVersion", "init", "render", "renderAsync", "renderProgressive", "shutdown", "validate"]
     assert out["abi"] == 1 and out["valid"] is True
     import torch
     if not torch.cuda.is_available():
@@ -44,6 +44,14 @@ def test_node_render_matches_reference_frames(built):
         assert f["type"] == "[object Uint8ClampedArray]", name
         assert f["diff"] <= 1, (name, f)
     assert out["constructed"] <= 1 and out["async"] <= 1
+    # progressive delivery (per-tile completion callbacks)
+    pr = out["progressive"]
+    assert pr["bandDiff"] <= 1 and pr["frameDiff"] <= 1
+    rows = [r for _, r in pr["bands"]]
+    assert [f for f, _ in pr["bands"]] == [sum(rows[:i]) for i in range(len(rows))] and sum(rows) == 135     # in order, gap-free
+    big = out["progressiveBig"]
+    assert big["length"] == 2048 * 1100 * 4 and big["same"] == 0
+    assert len(big["bands"]) == 8 and sum(r for _, r in big["bands"]) == 1100 and [f for f, _ in big["bands"]] == sorted(f for f, _ in big["bands"])
     assert out["counted"]["pixels"] == 240 * 135 and out["counted"]["rays"] > out["counted"]["pixels"]
     assert "sampler" in out["unsupported"]
 
@@ -66,6 +74,7 @@ def test_http_bridge_surface(built):
     import torch
     if not torch.cuda.is_available():
         assert out["frame"]["status"] == 503 and "no HIP device" in out["frame"]["error"]
+        assert out["progressive"]["status"] == 503 and "no HIP device" in out["progressive"]["error"]
 
 
 @needs_node
@@ -74,3 +83,6 @@ def test_http_bridge_serves_reference_frame(built):
     out = _run_server_check()
     assert out["frame"]["status"] == 200 and out["frame"]["bytes"] == 240 * 135 * 4
     assert out["frame"]["diff"] <= 1 and float(out["frame"]["kernelMs"]) > 0
+    pr = out["progressive"]          # chunked response, one chunk per band, timings as trailers
+    assert pr["status"] == 200 and pr["bytes"] == 240 * 135 * 4 and pr["chunked"] == "chunked"
+    assert pr["sameAsWhole"] and float(pr["kernelMs"]) > 0
