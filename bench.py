@@ -92,6 +92,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a "Hostname / Librccl path" banner
+    # on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
+    # line alone goes to the real stdout, kept in `json_fd`.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails
     # (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept here so a bare launch works too.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -473,7 +480,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.scene, w, h)
             except Exception as e:   # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     renderer.close()
     if p2p:
