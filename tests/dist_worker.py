@@ -52,17 +52,30 @@ def main():
         sc = dict(scene_d)
         sc["segs"] = 1 + (f % 3)
         blobs.append(rt_host.flatten_scene(sc))
-    send = torch.zeros((world, plan.band_rows, w, 3), dtype=torch.uint8)
+    # as in bench.py, the bands of EVERY = 2 consecutive steps share one exchange: send[f, j] is this rank's band of the
+    # frame that rank f owns in step j; step j's frames differ from step 0's (the scene with one more bounce)
+    EVERY = 2
+    blobs2 = []
     for f in range(world):
-        if rows:
-            data = np.frombuffer(ou.c_oracle_rows(blobs[f], w, h, rows), dtype=np.uint8).reshape(len(rows), w, 4)
-            send[f, :len(rows)] = torch.from_numpy(data[..., :3].copy())
+        sc = dict(scene_d)
+        sc["segs"] = 2 + (f % 3)
+        blobs2.append(rt_host.flatten_scene(sc))
+    per_step = [blobs, blobs2]
+    send = torch.zeros((world, EVERY, plan.band_rows, w, 3), dtype=torch.uint8)
+    for j in range(EVERY):
+        for f in range(world):
+            if rows:
+                data = np.frombuffer(ou.c_oracle_rows(per_step[j][f], w, h, rows), dtype=np.uint8).reshape(len(rows), w, 4)
+                send[f, j, :len(rows)] = torch.from_numpy(data[..., :3].copy())
     recv = torch.empty_like(send)
     shard.exchange_bands(send, recv, async_op=True).wait()
-    mine = torch.empty((h, w, 4), dtype=torch.uint8)
-    shard.deinterleave(plan, recv, mine)
-    whole = np.frombuffer(ou.c_oracle_render(blobs[rank], w, h), dtype=np.uint8).reshape(h, w, 4)
-    ok2 = torch.tensor([int(np.array_equal(mine.numpy(), whole))])
+    same = 1
+    for j in range(EVERY):
+        mine = torch.empty((h, w, 4), dtype=torch.uint8)
+        shard.deinterleave(plan, recv[:, j], mine)                 # a strided view: the rank stride is EVERY bands
+        whole = np.frombuffer(ou.c_oracle_render(per_step[j][rank], w, h), dtype=np.uint8).reshape(h, w, 4)
+        same &= int(np.array_equal(mine.numpy(), whole))
+    ok2 = torch.tensor([same])
     dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("DIST_RESULT_A2A world=%d identical=%d" % (world, int(ok2.item())), flush=True)
