@@ -311,14 +311,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #define RT_LOAD(TAB, I) rt_geom{(TAB)[I].ox, (TAB)[I].oy, (TAB)[I].oz, (TAB)[I].r2}
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
       // the compiler's runtime unrolling); the two s_load_dwordx8 of a pair are issued together.
-#if !RT_STRICT
   if (segs_left != 0) {
         // Primary rays.  First a wave-wide cull: lane j compares sphere j's conservative screen rectangle
         // (host, resolution-independent: bounds of X/D and Y/D over the pixels whose LINE meets the sphere)
         // with the rectangle of this wave's 8x8 pixel block; __ballot turns the 64 verdicts into one scalar
         // mask and only the surviving spheres are tested, in index order (the tie-break is preserved).
-        // A wave of sky pixels tests nothing; a wave of floor pixels tests the floor.
-        const geom_kptr ga = (geom_kptr)L.geom_cam;
+        // A wave of sky pixels tests nothing; a wave of floor pixels tests the floor.  The cull only prunes, so the strict
+        // kernel uses it too (with the reference's own discriminant for the survivors) and stays bit-identical.
+        [[maybe_unused]] const geom_kptr ga = (geom_kptr)L.geom_cam;
         for (uint32_t base = 0; base < NLOOP; base += 64u) {
           const uint32_t j = base + lane;
           const rt_geom cr = cull[j < NLOOP ? j : 0u];                   // LDS: {x_lo, x_hi, y_lo, y_hi} in units of 1/D
@@ -328,15 +328,17 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           while (m) {
             const uint32_t i = base + (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
+#if RT_STRICT
+            const rt_geom g0 = RT_LOAD(geom, i);
+            RT_GENERIC(i, g0)
+#else
             const rt_geom g0 = RT_LOAD(ga, i);
             RT_ANCHORED(i, g0)
+#endif
           }
         }
   }
-  bool searched = true;                // the primary ray's candidates were found above (camera-anchored, culled)
-#else
-  bool searched = false;
-#endif
+  bool searched = true;                // the primary ray's candidates were found above (culled; camera-anchored in the product kernel)
 
   if (segs_left != 0) {
     for (;;) {
