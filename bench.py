@@ -29,7 +29,10 @@ step is one frame's worth of pixels at every N (weak scaling).  Two plans put th
     Gpixel/s), the peer-store plan 5 % (65.2; its workgroups transpose their tile through LDS to store whole lines).  It ships the alpha byte, so it needs 4.1 MB per link per step at
     N=8 (33 GB/s, half a link) but would be link-bound below N=6.  Set-up and a one-step PRE-FLIGHT (every rank
     checks the frame it owns against the reference's rows) run first; any failure on any rank makes all ranks
-    fall back to the all-to-all plan, and the JSON says so.  RT_BENCH_P2P=1/0 forces a plan.
+    fall back to the all-to-all plan, and the JSON says so.  Then BOTH plans are timed for a few groups of steps
+    and the faster one (slowest rank decides) runs the measurement: the choice is made by the node itself, not by
+    the estimate above (`config.plan_calibration_ms_per_step`).  RT_BENCH_P2P=1/0 forces a plan, =auto calibrates
+    at any N.
 
 The scene is resident in HBM before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6,
 never here).
@@ -143,14 +146,19 @@ def main():
     # N>1: the bands cross xGMI as RGB24 (the alpha byte is the constant 255, main.js:198; the de-interleave on the
     # receiving rank restores it) — a quarter less link time, which is what bounds N=2 and N=4.
     # RT_BENCH_RGBA_EXCHANGE=1 ships RGBA8 instead (A/B).
-    # Which plan reassembles the frames (see below): peer stores when a rank's share of a frame per link is small enough
-    # not to be link-bound (N >= 6: 4.1 MB per link per step at N=8 against 12.4 MB of RGB24 at N=2), else the all-to-all
-    # with RGB24 bands, which ships a quarter fewer bytes.  RT_BENCH_P2P=1 / 0 forces one or the other.
+    # Which plan reassembles the frames (see below).  The all-to-all plan is always set up.  From N=6 on - where a rank's
+    # share of a frame per link is small enough for RGBA8 not to be link-bound (4.1 MB per link per step at N=8 against
+    # 12.4 MB of RGB24 at N=2) - the peer-store plan is set up as well, proves itself in a pre-flight, and then BOTH plans
+    # are timed for a few groups of steps and the faster one runs the measurement.  RT_BENCH_P2P=1 / 0 forces a plan.
     p2p_env = os.environ.get("RT_BENCH_P2P")
-    p2p = multi and (p2p_env == "1" or (p2p_env is None and world >= 6))
-    channels = 3 if (multi and not p2p and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
-    plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
-    batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
+    if p2p_env == "auto":                                                         # set both up and calibrate, at any N
+        p2p_env = None
+        p2p = multi
+    else:
+        p2p = multi and (p2p_env == "1" or (p2p_env is None and world >= 6))     # try to set the peer-store plan up
+    a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+    plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
+    batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
     # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
     # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
     # N>1: the render stream gets HIGH priority, so the exchange's copy kernels and the de-interleave (normal priority,
@@ -249,16 +257,15 @@ def main():
             if my_buf:
                 lib.rt_free_device(dev_index, my_buf)
             p2p = False
-            channels = 3 if (w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
-            plan = shard.TilePlan(w, h, TILE_ROWS, world, channels)
-            batch_flags = flags | (rt_host.RT_FLAG_RGB24 if channels == 3 else 0)
         else:
             token = torch.zeros(1, dtype=torch.int32, device="cpu" if rehearse else dev)
-    if multi and not p2p:
+    # `mode["p2p"]`: the plan the step machinery below uses right now (the calibration switches it back and forth)
+    mode = {"p2p": p2p}
+    if multi and not (p2p and p2p_env == "1"):
         # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
-        send = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        host_recv = torch.empty((world, every, plan.band_rows, w, channels), dtype=torch.uint8) if rehearse else None
+        send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
     pending = []      # (work, slot, steps in it) of exchanges in flight; at most 2
     group = {"slot": 0, "fill": 0}                                 # the exchange buffer being filled, and how many steps are in it
     # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
@@ -269,17 +276,17 @@ def main():
     def render_step(slot, j=0):
         if not multi:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
-        elif p2p:   # frame f of this step -> rank f's buffer, slot `slot`, position j; rows in frame order
+        elif mode["p2p"]:   # frame f of this step -> rank f's buffer, slot `slot`, position j; rows in frame order
             off = (slot * every + j) * frame_bytes
             renderer.render_scatter(w, h, [b + off for b in peer_buf], my_tiles, stream=stream, flags=flags)
         else:   # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
             renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
 
     def finish(item):
-        work, slot, count = item
+        work, slot, count, was_p2p = item
         with torch.cuda.stream(side):
             work.wait()                                          # the side stream waits for the exchange (p2p: the barrier)
-            if p2p:
+            if was_p2p:
                 count = 0                                        # the frames are already whole, in place
             elif rehearse:
                 recv[slot].copy_(host_recv)
@@ -290,7 +297,7 @@ def main():
 
     def launch_exchange():
         slot = group["slot"]
-        if p2p:
+        if mode["p2p"]:
             if rehearse:
                 torch.cuda.synchronize()                          # gloo knows nothing of the GPU: finish the stores first
             work = dist.all_reduce(token, async_op=True)          # after every rank's stores of this group (stream order)
@@ -298,7 +305,7 @@ def main():
             work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
         else:
             work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
-        pending.append((work, slot, group["fill"]))              # overlaps with the renders of the next group
+        pending.append((work, slot, group["fill"], mode["p2p"]))   # overlaps with the renders of the next group
         group["last_slot"] = slot
         group["slot"], group["fill"] = slot ^ 1, 0
 
@@ -333,6 +340,28 @@ def main():
     step(0)
     drain()
     fence()
+
+    # Both plans are set up (N >= 6, nothing forced): time a few groups of steps with each and keep the faster one.  The
+    # slower rank decides (MAX over ranks), so every rank makes the same choice.
+    calibration = None
+    if multi and p2p and p2p_env is None:
+        def timed(n):
+            fence()
+            t0 = time.perf_counter()
+            for k in range(n):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        calibration = {}
+        for name, flag in (("all_to_all", False), ("peer_stores", True)):
+            mode["p2p"] = flag
+            timed(every)                                   # this plan's own first-use costs
+            calibration[name] = round(timed(8 * every) / (8 * every) * 1e3, 4)      # ms per step
+        mode["p2p"] = calibration["peer_stores"] <= calibration["all_to_all"]
+        fence()
     for k in range(args.warmup):
         step(k)
     drain()
@@ -349,6 +378,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    channels = 4 if (not multi or mode["p2p"]) else a2a_channels          # bytes per pixel the chosen plan's launches store
     # ---- dominant kernel: average launch duration, HIP events on the launch stream.  At N=1 the timed region IS a train of
     #      these launches on this stream, so two events around the region give the average over every launch of it (what
     #      rocprofv3's per-kernel average of the same command shows); at N>1 the region also waits for slots, so the kernel is
@@ -381,7 +411,7 @@ def main():
     import oracle_util as ou
 
     def reassembled(j):
-        if not p2p:
+        if not mode["p2p"]:
             return frames[j].cpu().numpy()
         host = np.empty((h, w, 4), dtype=np.uint8)
         if lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf + (group["last_slot"] * every + j) * frame_bytes, frame_bytes) != 0:
@@ -418,7 +448,7 @@ def main():
                 traffic = tj[key]["hbm_bytes_per_launch"]
         if not multi:
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
-        elif p2p:
+        elif mode["p2p"]:
             how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
                    "frame buffer of the rank that owns each frame (peer-mapped over xGMI, RGBA8, rows in place): no data collective, no "
                    "de-interleave; one all_reduce per %d steps is the barrier" % (world, TILE_ROWS, world, every))
@@ -468,7 +498,9 @@ def main():
         }
         if p2p_note:
             out["config"]["plan_note"] = p2p_note
-        if multi and p2p:
+        if calibration:
+            out["config"]["plan_calibration_ms_per_step"] = calibration
+        if multi and mode["p2p"]:
             out["exchange"] = {"plan": "peer stores (rt_render_scatter_device through IPC-mapped frame buffers)", "collective": "all_reduce of one int per group (barrier)",
                                "bytes_stored_remotely_per_rank_per_step": (world - 1) * plan.pixels_of(rank) * 4, "steps_per_barrier": every}
         elif multi:
