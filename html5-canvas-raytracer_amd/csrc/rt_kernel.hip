@@ -247,6 +247,12 @@ template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3
 // was accumulated above it (S, O, LO, HI), to be restored when its reflection subtree has been evaluated.
 struct park { double amb[3], ds[3], a3, a4, h[3], f[3], S, O[3], LO[3], HI[3]; uint32_t path, segs_left; int level, map_valid, hcode; };
 
+__device__ __forceinline__ rt_geom rt_load_geom32(geom_kptr tab, uint32_t i) {
+  const rt_geom __attribute__((address_space(4))) *g =
+      (const rt_geom __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)tab + (i << 5));
+  return rt_geom{g->ox, g->oy, g->oz, g->r2};
+}
+
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
@@ -308,7 +314,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const double disc_ = __builtin_fma(tca_, tca_, -(G).r2);                              \
         RT_CAND(IDX, tca_, disc_)                                                             \
       }
-#define RT_LOAD(TAB, I) rt_geom{(TAB)[I].ox, (TAB)[I].oy, (TAB)[I].oz, (TAB)[I].r2}
+      // 32-bit byte offset (at most 256 spheres x 32 bytes, times at most 16 lights in the light-anchored table): base +
+      // zext(offset) lets the scalar load take its offset from an SGPR (s_load_dwordx8 s[..], s[base], s_off) instead of
+      // a 64-bit address computation per load (+0.8 % on the headline)
+#define RT_LOAD(TAB, I) rt_load_geom32((TAB), (uint32_t)(I))
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
       // the compiler's runtime unrolling); the two s_load_dwordx8 of a pair are issued together.
   if (segs_left != 0) {
