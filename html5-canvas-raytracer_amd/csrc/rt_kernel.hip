@@ -520,13 +520,15 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             bool blocked = false;
 #if !RT_STRICT
             // walked from the light: origin = light k (uniform), direction = -sv, the hit point is at llen
-            const geom_kptr gl = (geom_kptr)L.geom_light + (size_t)k * L.n_objects;
+            const geom_kptr gl = (geom_kptr)L.geom_light;
+            const uint32_t glo = k * L.n_objects;                      // light k's table: a 32-bit index offset (RT_LOAD)
 #define RT_SDISC(G, TC, DISC)                                                                 \
             const double TC = -(sv.x * (G).ox + sv.y * (G).oy + sv.z * (G).oz);               \
             const double DISC = __builtin_fma(TC, TC, -(G).r2);
 #define RT_SROOTS(TC, THC, T0, T1) const double T0 = llen - (TC + THC), T1 = llen - (TC - THC);
 #else
             const geom_kptr gl = geom;
+            const uint32_t glo = 0u;
 #define RT_SDISC(G, TC, DISC)                                                                 \
             const v3 Lv_ = mk((G).ox - h.x, (G).oy - h.y, (G).oz - h.z);                      \
             const double TC = dot(sv, Lv_);                                                   \
@@ -609,7 +611,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
                 while (cand) {
                   const uint32_t j = (wd << 6) + (uint32_t)__builtin_ctzll(cand);
                   cand &= cand - 1ull;
-                  const rt_geom g0 = RT_LOAD(gl, j);
+                  const rt_geom g0 = RT_LOAD(gl, glo + j);
                   RT_SHADOW_U(j, g0)                                                          // the grid variant never counts
                 }
               }
@@ -619,20 +621,20 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
               if (li != 0.0) {
                 uint32_t j = 0;
                 for (; j + 2 <= NS; j += 2) {
-                  const rt_geom g0 = RT_LOAD(gl, j), g1 = RT_LOAD(gl, j + 1);
+                  const rt_geom g0 = RT_LOAD(gl, glo + j), g1 = RT_LOAD(gl, glo + j + 1);
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
-                if (j < NS) { const rt_geom g0 = RT_LOAD(gl, j); RT_SHADOW_U(j, g0) }
+                if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
               }
             } else
             if (COUNT || li != 0.0) {                  // li == 0 on entry (an earlier light was blocked) cannot change
               uint32_t j = 0;
               for (; j + 2 <= NS; j += 2) {
-                const rt_geom g0 = RT_LOAD(gl, j), g1 = RT_LOAD(gl, j + 1);
+                const rt_geom g0 = RT_LOAD(gl, glo + j), g1 = RT_LOAD(gl, glo + j + 1);
                 RT_SHADOW(j, g0) RT_SHADOW(j + 1, g1)
                 if (blocked) break;
               }
-              if (j < NS && !blocked) { const rt_geom g0 = RT_LOAD(gl, j); RT_SHADOW(j, g0) }
+              if (j < NS && !blocked) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW(j, g0) }
             }
 #undef RT_SHADOW
 #undef RT_SHADOW_U
