@@ -502,7 +502,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           double li = L.light_intensity;                               // shared across lights (q2)
           for (uint32_t k = 0; k < NL; k++) {
             double llen;
-            const v3 sraw = mk(L.lights[k][0] - h.x, L.lights[k][1] - h.y, L.lights[k][2] - h.z);
+            // light k from the kernarg segment through a 32-bit byte offset (scalar load with an SGPR offset)
+            const double *lk = (const double *)((const char *)&L.lights[0][0] + (uint32_t)(k * 24u));
+            const v3 sraw = mk(lk[0] - h.x, lk[1] - h.y, lk[2] - h.z);
             const double lmag = dot(sraw, sraw);
 #if RT_STRICT
             const v3 sv = unit(sraw, &llen);
