@@ -247,6 +247,12 @@ template <> struct frame<true>  { double amb[3], ds[3], a3, a4, h[3], f[3], re[3
 // was accumulated above it (S, O, LO, HI), to be restored when its reflection subtree has been evaluated.
 struct park { double amb[3], ds[3], a3, a4, h[3], f[3], S, O[3], LO[3], HI[3]; uint32_t path, segs_left; int level, map_valid, hcode; };
 
+// 64-bit table word `i` of a scalar-loaded bit-set table (shadow grids, bounce table: a few MB at most)
+__device__ __forceinline__ unsigned long long rt_load_word32(const void *base, uint32_t i) {
+  const char __attribute__((address_space(4))) *b = (const char __attribute__((address_space(4))) *)base;
+  return *(const unsigned long long __attribute__((address_space(4))) *)(b + (i << 3));
+}
+
 __device__ __forceinline__ rt_geom rt_load_geom32(geom_kptr tab, uint32_t i) {
   const rt_geom __attribute__((address_space(4))) *g =
       (const rt_geom __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)tab + (i << 5));
@@ -375,14 +381,13 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             const uint32_t face = (bx ? 0u : (by ? 2u : 4u)) + ((dm < 0.0) ? 1u : 0u);
             const uint32_t key = from * RT_BCELLS + face * (RT_BGRID * RT_BGRID) + (uint32_t)fv * RT_BGRID + (uint32_t)fu;
             const uint32_t words = (NLOOP + 63u) >> 6;
-            const unsigned long long __attribute__((address_space(4))) *tab = (const unsigned long long __attribute__((address_space(4))) *)L.bounce_table;
             ht = RT_INF; hcode = -1;
             for (uint32_t wd = 0; wd < words; wd++) {
               unsigned long long cand = 0ull, todo = __ballot(true);
               uint32_t distinct = 0;
               while (todo) {
                 const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
-                cand |= tab[(size_t)k0 * words + wd];
+                cand |= rt_load_word32(L.bounce_table, k0 * words + wd);
                 todo &= ~__ballot(key == k0);
                 if (++distinct == 16u && todo) {           // a wave whose rays fan out over many cells: scan everything
                   cand = (wd + 1u == words && (NLOOP & 63u)) ? ((1ull << (NLOOP & 63u)) - 1ull) : ~0ull;
@@ -600,14 +605,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
               const bool proj = (vz > 0.0) && (fx == fx) && (fy == fy);
               const uint32_t cell = proj ? (uint32_t)fy * RT_SGRID + (uint32_t)fx : (uint32_t)(RT_SGRID * RT_SGRID);   // last cell: every sphere
               const uint32_t words = (NLOOP + 63u) >> 6;
-              const unsigned long long __attribute__((address_space(4))) *cells =
-                  (const unsigned long long __attribute__((address_space(4))) *)((const double __attribute__((address_space(4))) *)L.shadow_grid + 16u * NL) +
-                  (size_t)k * (RT_SGRID * RT_SGRID + 1u) * words;
+              const uint32_t cells_at = 16u * NL + k * (RT_SGRID * RT_SGRID + 1u) * words;      // in 64-bit words from the grid's start
               for (uint32_t wd = 0; wd < words; wd++) {
                 unsigned long long cand = 0ull, todo = __ballot(true);
                 while (todo) {
                   const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)__builtin_ctzll(todo));
-                  cand |= cells[(size_t)c0 * words + wd];
+                  cand |= rt_load_word32(L.shadow_grid, cells_at + c0 * words + wd);
                   todo &= ~__ballot(cell == c0);
                 }
                 while (cand) {
