@@ -29,6 +29,14 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// A/B and test switches exist only in the TEST build of this library (csrc/Makefile: librt_hip_test.so, -DRT_TESTING,
+// selected by the tests with RT_HIP_LIB).  The product library reads no environment variable on the render path.
+#ifdef RT_TESTING
+#define RT_TEST_ENV(name) getenv(name)
+#else
+#define RT_TEST_ENV(name) ((const char *)nullptr)
+#endif
+
 int fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -71,6 +79,7 @@ struct lib_state {
   // Everything else of the multi-GPU frame - tile plan, per-device scenes and streams, RGB24 bands, de-interleave -
   // runs as on a real node.
   bool emulated = false;
+  bool all_visible = false;
 } G;
 
 int ensure_device(int d) {
@@ -105,6 +114,7 @@ struct rt_scene_dev {
   unsigned lds_bytes;
   double lights[RT_MAX_LIGHTS][3];   // host copy: lights travel in the kernarg segment
   uint32_t enclosing;            // sphere that strictly contains everything else (a skybox), or ~0u
+  bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
 };
 
 // ------------------------------------------------------------------------------------ lifetime
@@ -113,14 +123,21 @@ extern "C" const char *rt_last_error(void) { return g_err; }
 
 extern "C" int rt_init(int max_devices) {
   std::lock_guard<std::mutex> lk(G.mu);
-  if (G.inited) return RT_OK;
+  if (G.inited) {
+    // a second rt_init must not silently change how rt_render shards a frame: asking for a different number of GPUs than
+    // the library already uses is an error (0 = "whatever is in use" is fine); rt_shutdown first to change it
+    if (max_devices > 0 && max_devices != (int)G.dev.size() && !(max_devices > (int)G.dev.size() && G.all_visible))
+      return fail(RT_ERR_STATE, "rt_init(%d): the library is already initialised with %d device(s); call rt_shutdown first", max_devices, (int)G.dev.size());
+    return RT_OK;
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
     return fail(RT_ERR_DEVICE, "no HIP device visible (%s); this library has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e));
-  const char *emu = getenv("RT_EMULATE_DEVICES");
+  const char *emu = RT_TEST_ENV("RT_EMULATE_DEVICES");
   G.emulated = emu && atoi(emu) > 1;
   if (G.emulated) n = atoi(emu);
+  G.all_visible = !(max_devices > 0 && n > max_devices);   // every visible GPU is in use: a later request for "up to more" changes nothing
   if (max_devices > 0 && n > max_devices) n = max_devices;
   if (n > 16) n = 16;
   G.dev.resize(n);
@@ -404,6 +421,23 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
   for (uint32_t i = 0; i < hd->n_objects; i++) if (ob[i].albedo[4] > 0.0) s->refract = true;
+  // Scenes whose picture hinges on exact coincidences are rendered by the strict kernel throughout (the product kernel's
+  // short cuts - 1/r from the host, anchored discriminants, shadow rays walked from the light - assume a generic scene):
+  //   * a light exactly ON a sphere's surface (the reference's own `t < light_len`, main.js:297, then compares two numbers
+  //     that are equal up to rounding: a coin flip that only the reference's own arithmetic reproduces);
+  //   * a sphere with r2 <= 0 or not finite (no 1/r);
+  //   * a camera whose axis sums (main.js:187-191, quirk q1) have an exactly zero component: EVERY primary ray then lies in
+  //     a coordinate plane through the camera (see the centre row / column fix-up in render_batch_impl).
+  s->needs_strict = false;
+  for (int c = 0; c < 3; c++) if (hd->cam_axis_x[c] + hd->cam_axis_y[c] + hd->cam_axis_z[c] == 0.0) s->needs_strict = true;
+  for (uint32_t i = 0; i < hd->n_objects; i++) {
+    if (!(ob[i].r2 > 0.0) || !std::isfinite(ob[i].r2)) s->needs_strict = true;
+    const double *lt = (const double *)(base + hd->lights_offset);
+    for (uint32_t k = 0; k < hd->n_lights; k++) {
+      const double x = lt[3 * k] - ob[i].origin[0], y = lt[3 * k + 1] - ob[i].origin[1], z = lt[3 * k + 2] - ob[i].origin[2];
+      if (fabs((x * x + y * y + z * z) - ob[i].r2) <= 1e-9 * fmax(ob[i].r2, 1.0)) s->needs_strict = true;
+    }
+  }
   s->lds_bytes = hd->n_objects * (unsigned)(sizeof(rt_sphere) + sizeof(rt_geom)) + RT_MAX_TEXTURES * (unsigned)sizeof(rt_texture_desc);
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
@@ -476,13 +510,13 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   {
     // shadow grids, in the loop order the product kernel uses (B when there is an enclosing sphere)
     const uint32_t n_loop = has_b ? NO - 1 : NO;
-    static const uint32_t sgrid_min = getenv("RT_SGRID_MIN") ? (uint32_t)atoi(getenv("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;   // A/B switch
+    static const uint32_t sgrid_min = RT_TEST_ENV("RT_SGRID_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;   // A/B switch
     if (n_loop > sgrid_min && hd->n_lights > 0) {
       const std::vector<uint64_t> sg = build_shadow_grid(has_b ? objs_b.data() : pob_a, n_loop, hd->n_lights, s->lights);
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
       if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     }
-    static const uint32_t btable_min = getenv("RT_BTABLE_MIN") ? (uint32_t)atoi(getenv("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;   // A/B switch
+    static const uint32_t btable_min = RT_TEST_ENV("RT_BTABLE_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;   // A/B switch
     if (n_loop > btable_min && hd->segs > 1) {      // rays bounce at all only from depth 2 on
       const std::vector<uint64_t> bt = build_bounce_table(has_b ? objs_b.data() : pob_a, NO, n_loop);
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_bounce_table, bt.size() * sizeof(uint64_t));
@@ -530,7 +564,37 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
 namespace {
 int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
                       void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats);
+#ifdef RT_TESTING
+thread_local struct { double *d_buf; uint32_t x, y; } g_probe = {nullptr, 0u, 0u};
+#endif
 }  // namespace
+
+#ifdef RT_TESTING
+// Test build only: the ray tree of ONE sample (sample-grid coordinates sx, sy) as RT_PROBE_NODES records of RT_PROBE_WORDS
+// doubles {path, hcode, t, hit point, normal, direction, sampled colour, diffuse, specular, segs left, light intensity after
+// the scans, ray origin, children mask, valid}; the row that holds the sample is rendered into scratch memory.
+extern "C" int rt_test_probe(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t sx, uint32_t sy, uint32_t flags, double *out_records) {
+  if (!s || !out_records) return fail(RT_ERR_INVALID, "rt_test_probe: NULL argument");
+  int rc = ensure_device(s->device);
+  if (rc) return rc;
+  const size_t bytes = (size_t)RT_PROBE_NODES * RT_PROBE_WORDS * sizeof(double);
+  double *d_probe = nullptr;
+  void *d_row = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_probe, bytes));
+  hipError_t e = hipMemset(d_probe, 0, bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_row, (size_t)w * 4u);
+  if (e != hipSuccess) { (void)hipFree(d_probe); return fail(RT_ERR_DEVICE, "rt_test_probe: %s", hipGetErrorString(e)); }
+  const uint32_t ss = s->hd.supersample;
+  rt_tiles t = {1u, sy / ss, 1u, 1u};
+  rt_stats st;
+  g_probe.d_buf = d_probe; g_probe.x = sx; g_probe.y = sy;
+  rc = rt_render_tiles_device(s, w, h, &t, d_row, nullptr, flags & ~(uint32_t)RT_FLAG_RGB24, &st);
+  g_probe.d_buf = nullptr;
+  if (!rc) { e = hipMemcpy(out_records, d_probe, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_test_probe: %s", hipGetErrorString(e)); }
+  (void)hipFree(d_probe); (void)hipFree(d_row);
+  return rc;
+}
+#endif
 
 extern "C" int rt_render_batch_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out,
                                       uint64_t frame_stride_bytes, void *hip_stream, uint32_t flags, rt_stats *stats) {
@@ -566,27 +630,43 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
 
   const rt_scene_header &hd = s->hd;
   const bool ss2 = hd.supersample == 2;
+  const bool count = (flags & RT_FLAG_COUNT) != 0;
+  // Which kernel.  The product (FMA) kernel unless the caller asks for the strict one - or the scene itself sits on an exact
+  // coincidence whose outcome in the reference is decided by the last bit of its own arithmetic (s->needs_strict, see
+  // rt_scene_upload): only the operation-for-operation kernel reproduces those.
+  const bool no_fixup = RT_TEST_ENV("RT_NO_FIXUP") != nullptr;                 // test build: the product kernel's own pixels everywhere (read per call)
+  const bool strict_main = (flags & RT_FLAG_STRICT_FP) != 0 || (s->needs_strict && !no_fixup);
+  const uint8_t *db = (const uint8_t *)s->d_blob;
+  static const bool no_grid = RT_TEST_ENV("RT_NO_SHADOW_GRID") != nullptr;     // A/B switches (test build only)
+  static const bool no_bounce = RT_TEST_ENV("RT_NO_BOUNCE_TABLE") != nullptr;
+  // RT_LDS_PAD (bytes): occupancy experiments only — extra dynamic LDS per workgroup caps the workgroups per CU
+  static const unsigned lds_pad = RT_TEST_ENV("RT_LDS_PAD") ? (unsigned)atoi(RT_TEST_ENV("RT_LDS_PAD")) : 0u;
   rt_launch L;
   memset(&L, 0, sizeof L);
-  const uint8_t *db = (const uint8_t *)s->d_blob;
-  // ordering B (enclosing sphere last, outside the loops) for the product kernel; the strict kernel and the
-  // counting variant walk the scene in its own order so that they stay literal / count what the reference counts
-  const bool order_b = s->d_objects_b && !(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT));
-  const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (3 + hd.n_lights) : 0);
-  L.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
+  // the part of the launch record that depends on the kernel: ordering B (enclosing sphere last, outside the loops) and the
+  // shadow grids / bounce table for the product kernel; the strict kernel and the counting variant walk the scene in its own
+  // order so that they stay literal / count what the reference counts
+  auto bind_kernel = [&](rt_launch &K, bool strict) {
+    const bool plain = strict || count;
+    const bool order_b = s->d_objects_b && !plain;
+    const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (3 + hd.n_lights) : 0);
+    K.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
+    K.geom = gt;
+    K.geom_cam = gt + hd.n_objects;
+    K.cull = gt + 2 * (size_t)hd.n_objects;
+    K.geom_light = gt + 3 * (size_t)hd.n_objects;
+    K.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
+    K.shadow_grid = (!plain && !no_grid) ? s->d_shadow_grid : nullptr;
+    K.bounce_table = (!plain && !no_bounce) ? s->d_bounce_table : nullptr;
+    K.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
+    K.enclosing = order_b ? hd.n_objects - 1 : ~0u;
+  };
+  auto lds_for = [&](bool strict) {
+    return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
+                                             : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
+  };
+  bind_kernel(L, strict_main);
   L.textures = s->d_texdesc;
-  L.geom = gt;
-  L.geom_cam = gt + hd.n_objects;
-  L.cull = gt + 2 * (size_t)hd.n_objects;
-  L.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
-  // the grids are built for the product kernel's order: B if the scene has an enclosing sphere, else the scene's own
-  static const bool no_grid = getenv("RT_NO_SHADOW_GRID") != nullptr;     // A/B switch for the profiles/ scripts
-  L.shadow_grid = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && !no_grid) ? s->d_shadow_grid : nullptr;
-  static const bool no_bounce = getenv("RT_NO_BOUNCE_TABLE") != nullptr;  // A/B switch
-  L.bounce_table = (!(flags & (RT_FLAG_STRICT_FP | RT_FLAG_COUNT)) && !no_bounce) ? s->d_bounce_table : nullptr;
-  L.geom_light = gt + 3 * (size_t)hd.n_objects;
-  L.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
-  L.enclosing = order_b ? hd.n_objects - 1 : ~0u;
   L.texel_base = db;
   L.out = (uint32_t *)d_out;
   L.counters = D.d_counters;
@@ -614,8 +694,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   L.scatter = d_frames ? 1u : 0u;
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
-  const bool count = (flags & RT_FLAG_COUNT) != 0;
+  L.win_w = L.win_h = ~0u;                                       // the whole frame
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
+#ifdef RT_TESTING
+  L.probe = g_probe.d_buf; L.probe_x = g_probe.x; L.probe_y = g_probe.y;
+#endif
 
   // timing events of a stats call; released on every way out of this function
   struct event_pair {
@@ -624,12 +707,39 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   } ev;
   hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
-  // RT_LDS_PAD (bytes): occupancy experiments only — extra dynamic LDS per workgroup caps the workgroups per CU
-  static const unsigned lds_pad = getenv("RT_LDS_PAD") ? (unsigned)atoi(getenv("RT_LDS_PAD")) : 0u;
-  const int err = ((flags & RT_FLAG_STRICT_FP) ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2,
-      s->lds_bytes + lds_pad + (!(flags & RT_FLAG_STRICT_FP) ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
-                                                             : RT_WG_THREADS * 8u),                           //   (strict: one slot, the scatter store's tile)
-      stream);
+  int err = (strict_main ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, lds_for(strict_main), stream);
+  // Centre row / centre column of a sample grid with an ODD number of rows / columns.  The primary rays there have a direction
+  // component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they spawn that stays in that
+  // plane - live in a coordinate plane through the camera, and a sphere centred on that plane (the reference's own scene has
+  // several) is met with a normal component of exactly 0: u or v lands exactly ON a texel / checker boundary (main.js:127-130,
+  // 344-347), and on which side the reference falls is decided by whether ITS OWN rounding noise (e.g. main.js:257-259 at
+  // refract_index 1, where q is 0 or 1e-16 depending on the last bit of cosi) pushed the ray off the plane.  No arithmetic
+  // but the reference's own reproduces such coin flips, so these samples - one row and one 8-pixel column group of the frame
+  // at most - are rendered by the strict kernel, on top of the product kernel's frame.
+  if (err == 0 && !strict_main && !no_fixup) {
+    const uint32_t ssf = ss2 ? 2u : 1u;
+    const bool odd_rows = ((h * ssf) & 1u) != 0, odd_cols = ((w * ssf) & 1u) != 0;
+    rt_launch F = L;
+    bind_kernel(F, true);
+    F.counters = D.d_counters;
+    if (odd_rows) {
+      const uint32_t crow = (h - 1u) / 2u, tc = crow / tiles->tile_rows;       // the output row that holds the centre sample row
+      if (tc >= tiles->tile_first && (tc - tiles->tile_first) % tiles->tile_stride == 0 && (tc - tiles->tile_first) / tiles->tile_stride < tiles->n_tiles) {
+        const uint32_t ti = (tc - tiles->tile_first) / tiles->tile_stride;
+        F.grid_x = 0u; F.bx0 = 0u;
+        F.grid_y = 1u; F.by0 = ti * L.rb_per_tile + (crow - tc * tiles->tile_rows) / rows_per_wg;
+        F.win_x0 = 0u; F.win_w = ~0u; F.win_y0 = crow; F.win_h = 1u;
+        err = rt_launch_trace_strict(&F, s->refract, 0, ss2, lds_for(true), stream);
+      }
+    }
+    if (err == 0 && odd_cols) {
+      const uint32_t ccol = (w - 1u) / 2u;
+      F.grid_x = 1u; F.bx0 = ccol / RT_TILE_W;
+      F.grid_y = 0u; F.by0 = 0u;
+      F.win_x0 = ccol & ~7u; F.win_w = 8u; F.win_y0 = 0u; F.win_h = ~0u;     // a whole 8-pixel group: the unit of the RGB24 store
+      err = rt_launch_trace_strict(&F, s->refract, 0, ss2, lds_for(true), stream);
+    }
+  }
   if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
   if (stats) {
     HIP_TRY(hipEventRecord(ev1, stream));

@@ -65,6 +65,18 @@ struct rt_launch {
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
   uint32_t *out_frames[RT_MAX_SCATTER];
+  // Fix-up launches (strict kernel only, rt_api.hip render_batch_impl): the grid starts at workgroup (bx0, by0) and only the
+  // pixels of the window [win_x0, win_x0 + win_w) x [win_y0, win_y0 + win_h) (frame coordinates) are stored.
+  uint32_t bx0, by0, win_x0, win_w, win_y0, win_h;
+  uint32_t grid_x, grid_y;           // host side only: the fix-up launch's grid (0 = the whole grid)
+#ifdef RT_TESTING
+  // test build only (librt_hip_test.so): per-node records of ONE sample's ray tree, for parity debugging
+  double *probe;                     // RT_PROBE_NODES records of RT_PROBE_WORDS doubles, or NULL
+  uint32_t probe_x, probe_y;         // the sample, in sample-grid coordinates
+#endif
 };
+
+#define RT_PROBE_WORDS 24u
+#define RT_PROBE_NODES 64u
 
 #endif

@@ -222,11 +222,15 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
   // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
   // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
-  const uint32_t tile_x = blockIdx.x;
+#if RT_STRICT
+  const uint32_t tile_x = blockIdx.x + L.bx0, by = blockIdx.y + L.by0;   // fix-up launches cover part of the grid (rt_device.h)
+#else
+  const uint32_t tile_x = blockIdx.x, by = blockIdx.y;
+#endif
   uint32_t tile_i, row_block;
-  if (L.n_tiles == 1u) { tile_i = 0u; row_block = blockIdx.y; }
-  else if (L.rb_shift != ~0u) { tile_i = blockIdx.y >> L.rb_shift; row_block = blockIdx.y & ((1u << L.rb_shift) - 1u); }
-  else { tile_i = blockIdx.y / L.rb_per_tile; row_block = blockIdx.y - tile_i * L.rb_per_tile; }
+  if (L.n_tiles == 1u) { tile_i = 0u; row_block = by; }
+  else if (L.rb_shift != ~0u) { tile_i = by >> L.rb_shift; row_block = by & ((1u << L.rb_shift) - 1u); }
+  else { tile_i = by / L.rb_per_tile; row_block = by - tile_i * L.rb_per_tile; }
   rt_pixel P;
   P.sub = 0u;                                          // trow = row inside tile `tile_i`
   if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = row_block * RT_TILE_H + (lane >> 3); }
@@ -234,6 +238,9 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
   P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
   P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
+#if RT_STRICT
+  P.valid = P.valid && (P.px - L.win_x0 < L.win_w) && (P.frow - L.win_y0 < L.win_h);
+#endif
   return P;
 }
 
@@ -263,7 +270,12 @@ template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
-                                            [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3]) {
+                                            [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3],
+                                            [[maybe_unused]] bool is_probe) {
+#ifdef RT_TESTING
+  uint32_t probe_n = 0;                                  // test build: nodes of this sample's ray tree recorded so far
+  double probe_li = 0.0;
+#endif
   const sphere_kptr objs = (sphere_kptr)L.objects;
   const geom_kptr geom = (geom_kptr)L.geom;
   const uint32_t N = L.n_objects, NL = L.n_lights;
@@ -283,7 +295,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
   [[maybe_unused]] uint32_t tree_path = 1u;            // general kernel: position in the ray tree (root 1, reflect 2p, refract 2p+1)
-#ifdef RT_ABLATE_BOUNCE
+#if defined(RT_TESTING) && defined(RT_ABLATE_BOUNCE)
   uint32_t segs_left = L.segs ? 1 : 0;
 #else
   uint32_t segs_left = L.segs;
@@ -430,11 +442,19 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       const int hi = hcode >> 1;
       const bool inside = (hcode & 1) != 0;
       bool descend = false;
-#ifdef RT_ABLATE_SHADE
+#if defined(RT_TESTING) && defined(RT_ABLATE_SHADE)
       if (true) { ret[0] = ht; ret[1] = (double)hcode; ret[2] = 0.0; } else
 #endif
       if (hcode < 0) {                                // main.js:231
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
+#ifdef RT_TESTING
+        if (is_probe && probe_n < RT_PROBE_NODES) {
+          double *q = L.probe + (size_t)(probe_n++) * RT_PROBE_WORDS;
+          for (uint32_t z = 0; z < RT_PROBE_WORDS; z++) q[z] = 0.0;
+          q[0] = (double)(REFRACT ? tree_path : (1u << level)); q[1] = -1.0; q[2] = ht; q[9] = d.x; q[10] = d.y; q[11] = d.z;
+          q[17] = (double)segs_left; q[19] = p.x; q[20] = p.y; q[21] = p.z; q[23] = 1.0;
+        }
+#endif
       } else {
         const rt_sphere &m = mtl[hi];                 // LDS, per-lane index
         // A2 ext part for the closest hit only (main.js:440-447; pure, so deferring it is exact)
@@ -454,7 +474,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         // A8 sampler (main.js:320).  Pure, so it is evaluated here, before the lighting, where few values
         // are live: the OCML atan2/asin bodies are the register-pressure peak of the kernel.
         double col[3];
-#ifdef RT_ABLATE_SAMPLER   /* timing experiments only (profiles/ab_build.sh); never defined in the product build */
+#if defined(RT_TESTING) && defined(RT_ABLATE_SAMPLER)   /* timing experiments only (profiles/ab_build.sh); never defined in the product build */
         const int kind = RT_SAMPLER_COLOR;
 #else
         const int kind = m.sampler_kind;
@@ -499,7 +519,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 
         // A7 lighting and shadows
         double diffuse = 0.0, specular = 0.0;
-#ifdef RT_ABLATE_LIGHT
+#if defined(RT_TESTING) && defined(RT_ABLATE_LIGHT)
         if (false) {
 #else
         if (a1 > 0.0 || a2 > 0.0) {
@@ -519,7 +539,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             const v3 sv = mk(sraw.x * inv_llen, sraw.y * inv_llen, sraw.z * inv_llen);
 #endif
             const double sdot = dot(sv, l);
-            if (sdot <= 0.0) continue;                                 // surface faces away
+#if RT_STRICT
+            if (sdot <= 0.0) continue;                                 // surface faces away (main.js:292)
+#else
+            if (!(sdot > 0.0)) continue;                               // the same; and a light AT the hit point: lmag == 0 makes sdot 0 there, NaN here
+#endif
             if (COUNT) cnt[1]++;
             // Shadow scan (main.js:293-304) over every sphere but the one just hit (q3).  A fully blocked lane
             // keeps li == 0 whatever follows, so leaving the loop is a pure shortcut, taken per pair.
@@ -579,9 +603,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
                 }                                                                           \
               }                                                                             \
             }
-#ifdef RT_ABLATE_SHADOW
+#if defined(RT_TESTING) && defined(RT_ABLATE_SHADOW)
             const uint32_t NS = 0;
-#elif defined(RT_ABLATE_SHADOW4)
+#elif defined(RT_TESTING) && defined(RT_ABLATE_SHADOW4)
             const uint32_t NS = NLOOP > 4u ? NLOOP - 4u : NLOOP;      // timing only: what skipping four tests per light would be worth
 #else
             const uint32_t NS = NLOOP;
@@ -652,7 +676,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #else
             diffuse += (li * sdot) * (inv_llen * inv_llen);            // 1/lmag = (1/llen)^2, already at hand
 #endif
-#ifdef RT_ABLATE_SPEC
+#if defined(RT_TESTING) && defined(RT_ABLATE_SPEC)
             if (false) {
 #else
             if (a2 > 0.0) {                                            // main.js:307-314
@@ -673,6 +697,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           }
           diffuse = min1(diffuse) * a1;
           specular = min1(specular) * a2;
+#ifdef RT_TESTING
+          probe_li = li;
+#endif
         }
 
         // A4 reflection direction.  (Computed AFTER the lighting: in program order the reference does it before, but it
@@ -708,6 +735,15 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         }
         const bool go_r = (rlen != 0.0);
         const bool go_f = REFRACT && (flen != 0.0);
+#ifdef RT_TESTING
+        if (is_probe && probe_n < RT_PROBE_NODES) {
+          double *q = L.probe + (size_t)(probe_n++) * RT_PROBE_WORDS;
+          q[0] = (double)(REFRACT ? tree_path : (1u << level)); q[1] = (double)hcode; q[2] = ht;
+          q[3] = h.x; q[4] = h.y; q[5] = h.z; q[6] = n.x; q[7] = n.y; q[8] = n.z; q[9] = d.x; q[10] = d.y; q[11] = d.z;
+          q[12] = col[0]; q[13] = col[1]; q[14] = col[2]; q[15] = diffuse; q[16] = specular; q[17] = (double)segs_left;
+          q[18] = probe_li; q[19] = p.x; q[20] = p.y; q[21] = p.z; q[22] = (double)(go_r ? 1 : 0) + 2.0 * (go_f ? 1 : 0); q[23] = 1.0;
+        }
+#endif
         if (!go_r && !go_f) {
           // children are absent or return [0,0,0] (segs == 0, main.js:221): x + 0*a == x
 #pragma unroll
@@ -917,7 +953,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const double lx = SS2 ? (double)(2u * ((lane >> 2) & 7u) + (sub & 1u)) : (double)(lane & 7u);
   const double ly = SS2 ? (double)(2u * (lane >> 5) + (sub >> 1)) : (double)(lane >> 3);
   const double blk_x0 = d0 - lx, blk_x1 = blk_x0 + bw, blk_y1 = d1 + ly, blk_y0 = blk_y1 - bh;
-  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt);
+#ifdef RT_TESTING
+  const bool is_probe = L.probe != nullptr && sx == L.probe_x && sy == L.probe_y && blockIdx.z == 0;
+#else
+  const bool is_probe = false;
+#endif
+  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe);
 
   // ---- A10 RGBA8 store ----
   uint32_t tid2 = threadIdx.x;
@@ -955,7 +996,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     const uint32_t px2 = P1.px - ((tid2 >> 6) * 8u + (lane2 & 7u)) + xr;
     const uint32_t dr = rr - (lane2 >> 3);              // row of the tile: difference in wrap-around arithmetic
     const uint32_t trow2 = P1.trow + dr, frow2 = P1.frow + dr;
-    if (px2 < L.w && trow2 < L.tile_rows && frow2 < L.h) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
+#if RT_STRICT
+    const bool in_win = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h);
+#else
+    const bool in_win = true;
+#endif
+    if (in_win && px2 < L.w && trow2 < L.tile_rows && frow2 < L.h) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
   } else if (!L.rgb24) {                               // wave-uniform
     if (valid && P1.sub == 0u) out[(size_t)orow * L.w + P1.px] = rgbw | 0xff000000u;
   } else {
@@ -971,7 +1017,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     const uint32_t word = (lo >> sh) | (hi << (24u - sh));
     const uint32_t x0 = P1.px - j;                     // first pixel of the group (a multiple of 8)
     const uint32_t in_row = (x0 + 8u <= L.w) ? 6u : ((x0 + 4u <= L.w) ? 3u : 0u);
+#if RT_STRICT
+    // a window's columns are whole 8-pixel groups (rt_api.hip), so the group's first pixel decides
+    const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h) && (x0 - L.win_x0 < L.win_w) && (P1.frow - L.win_y0 < L.win_h);
+#else
     const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h);
+#endif
     if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
   }
 
@@ -991,7 +1042,8 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned lds_bytes, hipStream_t stream) {
   // x: 32-pixel tiles across the frame; y: tiles x row blocks (8 rows, or 2 when supersampling); z: frames
   (void)ss2;
-  const dim3 grid(L->tiles_x, L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
+  // (a fix-up launch of the strict kernel covers part of that grid: L->grid_x / grid_y, when set)
+  const dim3 grid(L->grid_x ? L->grid_x : L->tiles_x, L->grid_y ? L->grid_y : L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
   // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
   const bool grid_variant = !RT_STRICT && !count && (L->shadow_grid != nullptr || L->bounce_table != nullptr);

@@ -19,6 +19,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SCENES_DIR = os.path.join(HERE, "scenes")
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(HERE, "csrc", "librt_hip.so")   # RT_HIP_LIB: A/B builds
+# The TEST build of the same sources (-DRT_TESTING): the only library that reads the A/B and test environment switches
+# (RT_EMULATE_DEVICES, RT_NO_BOUNCE_TABLE, RT_NO_FIXUP, ...) and exports rt_test_probe.  Tests select it with RT_HIP_LIB.
+TEST_LIB_PATH = os.path.join(HERE, "csrc", "librt_hip_test.so")
 
 RT_SCENE_MAGIC = 0x31535452
 RT_ABI_VERSION = 1
@@ -209,7 +212,8 @@ class Renderer:
         self.lib = lib or load_library()
         self.blob = scene if isinstance(scene, (bytes, bytearray)) else flatten_scene(scene)
         self.device = device
-        _check(self.lib, self.lib.rt_init(0), "rt_init")
+        if self.lib.rt_device_count() < 0:          # not initialised yet: use every visible GPU (an earlier rt_init's choice stands)
+            _check(self.lib, self.lib.rt_init(0), "rt_init")
         h = C.c_void_p()
         buf = C.create_string_buffer(self.blob, len(self.blob))
         _check(self.lib, self.lib.rt_scene_upload(device, buf, len(self.blob), C.byref(h)), "rt_scene_upload")

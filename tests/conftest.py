@@ -19,7 +19,7 @@ def built():
     """Make sure the native pieces exist (compiles them if this checkout has none yet)."""
     import rt_host
     import oracle_util
-    if not os.path.exists(rt_host.LIB_PATH) or not os.path.exists(oracle_util.C_ORACLE_PATH):
+    if not os.path.exists(rt_host.LIB_PATH) or not os.path.exists(rt_host.TEST_LIB_PATH) or not os.path.exists(oracle_util.C_ORACLE_PATH):
         import __graft_entry__
         __graft_entry__.build()
     return True
