@@ -1,51 +1,55 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg5]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload: BASELINE configs[2] — 3840x2160, the 8-sphere "H8" scene, 2 lights, depth 3 — at every N.
+--config cfg3 (default, the headline): BASELINE configs[2] — 3840x2160, the 8-sphere "H8" scene, 2 lights, depth 3.
+    N = 1: a step is ONE kernel launch writing one frame (the hot path, main.js:184-199 + :216-451, through the C ABI's
+    rt_render_tiles_device).  N > 1: a step is a BATCH of N frames, frame f ends up whole on rank f (weak scaling: per-GPU
+    work per step is one frame's worth of pixels at every N).
+--config cfg4: BASELINE configs[3] — ONE 7680x4320 H8 frame per step, row-tiled over the N ranks and whole on rank 0 after
+    one collective / barrier (strong scaling: the frame is fixed, per-GPU work shrinks with N).
+--config cfg5: BASELINE configs[4] — ONE 16384x16384 frame, 2x2 supersample, 64 spheres, depth 5, the same way.
 
-N = 1: a step is ONE kernel launch writing one 3840x2160 frame (the hot path, main.js:184-199 +
-:216-451, through the C ABI's rt_render_tiles_device).
+One process per GPU, torch.distributed backend "nccl" = RCCL over xGMI.  Every frame is sharded by interleaved 16-row tiles
+across the N ranks.  Two plans put a frame together on the rank that owns it:
 
-N > 1 (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI): a step is a BATCH of N
-frames.  Each frame is sharded by interleaved 16-row tiles across the N ranks; every rank renders its
-tiles of all N frames in one launch, and frame f ends up whole, RGBA8, in rank f's HBM.  Per-GPU work per
-step is one frame's worth of pixels at every N (weak scaling).  Two plans put the frames together:
+  * exchange plan (rt_render_batch_device + ONE collective + de-interleave): the bands cross the links as RGB24 - the alpha
+    byte is the constant 255 (main.js:198) and is restored by the de-interleave.  Batch mode (cfg3): one all_to_all_single
+    (band of frame f to rank f: all N(N-1) directed links at once; a gather to one root would be bound by that root's inbound
+    links).  Single-frame mode (cfg4/cfg5): one gather to rank 0.  The bands of 4 consecutive steps
+    (RT_BENCH_EXCHANGE_EVERY) share one collective, because issuing a c10d collective costs the host about as much as a
+    step's GPU work; a group's exchange overlaps the renders of the next group (two slots, side stream).
+  * peer stores (rt_render_scatter_device): every rank's kernel stores its tiles of a frame straight into the owning rank's
+    frame buffer - peer-mapped once through IPC handles - rows in frame order, RGBA8, whole 128-byte lines.  No data
+    collective, no send/recv buffers, no de-interleave: one all_reduce of one int per group of steps is the barrier.
+    Set-up and a one-step PRE-FLIGHT (every owner checks its frame against the reference's rows) run first; any failure on
+    any rank makes all ranks fall back to the exchange plan, and the JSON says so.  Default from N=6 in batch mode and at
+    any N>1 in single-frame mode; then BOTH plans are timed for a few groups of steps and the faster one (slowest rank
+    decides) runs the measurement (`config.plan_calibration_ms_per_step`).  RT_BENCH_P2P=1/0 forces a plan, =auto
+    calibrates at any N.
 
-  * all-to-all (default for N < 6; rt_render_batch_device + ONE all_to_all_single + de-interleave): the bands
-    cross the links as RGB24 - the alpha byte is the constant 255 (main.js:198) and is restored by the
-    de-interleave - a quarter off the link time that bounds N=2 and N=4; the bands of 4 consecutive steps
-    (RT_BENCH_EXCHANGE_EVERY) share one collective, because issuing a c10d collective costs the host about as much
-    as a step's GPU work (57 us measured against a 0.12 ms kernel); a group's exchange overlaps the renders of
-    the next group (two slots, side stream).  Uses all N(N-1) directed links at once (a gather to one root would
-    be bound by that root's inbound links: at ~60 Gpixel/s a GPU produces ~250 GB/s of pixels).
-  * peer stores (default for N >= 6; rt_render_scatter_device): every rank's kernel stores its tiles of frame f
-    straight into rank f's frame buffer - peer-mapped once through IPC handles - rows in frame order, RGBA8; a tile
-    row is whole 128-byte lines written by one workgroup.  No data collective, no send/recv buffers, no RCCL copy
-    kernels, no de-interleave: one all_reduce of one int per group of steps is the barrier.  Measured on ONE GPU
-    with one rank (RT_BENCH_FORCE_EXCHANGE=1): the all-to-all plan's own machinery costs 13 % (59 vs 68.7
-    Gpixel/s), the peer-store plan 5 % (65.2; its workgroups transpose their tile through LDS to store whole lines).  It ships the alpha byte, so it needs 4.1 MB per link per step at
-    N=8 (33 GB/s, half a link) but would be link-bound below N=6.  Set-up and a one-step PRE-FLIGHT (every rank
-    checks the frame it owns against the reference's rows) run first; any failure on any rank makes all ranks
-    fall back to the all-to-all plan, and the JSON says so.  Then BOTH plans are timed for a few groups of steps
-    and the faster one (slowest rank decides) runs the measurement: the choice is made by the node itself, not by
-    the estimate above (`config.plan_calibration_ms_per_step`).  RT_BENCH_P2P=1/0 forces a plan, =auto calibrates
-    at any N.
+The scene is resident in HBM before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
 
-The scene is resident in HBM before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6,
-never here).
+Before the W warm-up steps the GPU is brought to steady clocks: trains of launches until two consecutive trains agree within
+1 % (at least 50 ms), so a short timed region (the driver's --steps 20) measures the steady-state kernel.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the HBM-store roofline the
-metric names (4 algorithmic bytes per pixel); the path is FP64-VALU bound, so `fp64_valu` prices it
-against the binding bound.  `cpu_baseline` is the oracle's JS restatement (bit-identical to main.js, see
-tests/test_oracle.py) on one host thread over a bounded sample of rows of the same frame (N=1 only).
+Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the HBM-store roofline the metric names (4 algorithmic
+bytes per pixel); `roofline.traffic` and `fp64_valu.measured` come from rocprofv3 PMC passes over a short child run of this
+same command (N=1; --no-pmc or a missing rocprofv3 fall back to the committed profile and say so).  The path is FP64-VALU bound,
+so `fp64_valu` prices it against that bound: `measured` from the SQ_INSTS_VALU_*_F64 counters, `model` from the reference's
+algorithmic operation count.  `cpu_baseline` is the oracle's JS restatement (bit-identical to main.js, tests/test_oracle.py)
+on one host thread over a bounded sample of the same frame (N=1 only).
 """
 import argparse
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -55,20 +59,27 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (FMA) peak = half the 157.3 TF FP32 vector rate
 TILE_ROWS = 16
-FRAME_W, FRAME_H = 3840, 2160
+CONFIGS = {   # name: (scene, width, height, one frame per step shared by all ranks?)
+    "cfg3": ("h8", 3840, 2160, False),
+    "cfg4": ("h8", 7680, 4320, True),
+    "cfg5": ("lcg64", 16384, 16384, True),
+}
 
 
 def cpu_baseline(scene_name, w, h):
     """Oracle leg (checker code, timed beside the GPU; never on the product path)."""
     import oracle_util as ou
-    rows, reps = h, 4              # whole frames, ~10 s of single-thread CPU work at ~4 Mpixel/s
+    px_target = 4 * 3840 * 2160            # ~10 s of single-thread CPU work at ~4 Mpixel/s on the headline scene
+    rows = min(h, max(8, px_target // w))
+    reps = max(1, px_target // (rows * w))
     if ou.node_path():
         r = ou.node_cli("time", ou.scene_json(scene_name), w, h, rows, reps, timeout=900)
+        what = ("%d whole %dx%d frames" % (reps, w, h)) if rows == h else ("%d evenly spaced rows of the %dx%d frame, %d times" % (rows, w, h, reps))
         return {"value": round(r["mpixel_per_s"], 4), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-                "sample": "%d whole %dx%d frames (%d pixels, %.1f s), oracle/restate.js (bit-identical to main.js) under node %s, 1 thread, "
-                          "after an untimed JIT warm-up pass over a quarter of the rows" % (reps, w, h, r["pixels"], r["ms"] / 1e3, r["node"]),
+                "sample": "%s (%d pixels, %.1f s), oracle/restate.js (bit-identical to main.js) under node %s, 1 thread, "
+                          "after an untimed JIT warm-up pass over a quarter of the rows" % (what, r["pixels"], r["ms"] / 1e3, r["node"]),
                 "mray_per_s": round(r["rays"] / r["ms"] / 1e3, 4), "host_cpus": os.cpu_count(),
-                "reference_ratio": "the reference's own main.js cannot travel to this box; in the build container it needs 10.57 s for this frame "
+                "reference_ratio": "the reference's own main.js cannot travel to this box; in the build container it needs 10.57 s for the 3840x2160 H8 frame "
                                    "against 2.73 s for restate.js (same SHA-256): the allocation-free restatement is 3.9x FASTER than main.js, "
                                    "so this baseline flatters the CPU by that factor"}
     import rt_host
@@ -83,17 +94,69 @@ def cpu_baseline(scene_name, w, h):
             "host_cpus": os.cpu_count()}
 
 
+def pmc_passes(argv, kernel_substr="rt_trace"):
+    """rocprofv3 counter passes over a short CHILD run of this same command (N=1): HBM bytes per launch (WRITE_SIZE, FETCH_SIZE in
+    separate passes - they do not fit one - with the guide's gfx950 correction: FETCH_SIZE counts half the bytes) and the FP64
+    VALU instruction counters.  Returns (dict, note); every failure is reported in the note and leaves the values None."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    import csv
+    import glob
+    out = {}
+    passes = [("WRITE_SIZE",), ("FETCH_SIZE",), ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU", "SQ_INSTS_SALU")]
+    env = dict(os.environ, TMPDIR="/tmp", RT_BENCH_CHILD="1", RT_BENCH_NO_SETTLE="1")     # counters do not depend on clocks: no need to settle them
+    for counters in passes:
+        d = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), *argv,
+                   "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counters[0], r.returncode, (r.stderr or r.stdout)[-300:])
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc %s wrote no counter_collection.csv" % counters[0]
+            sums, launches = {}, {}
+            for fpath in files:
+                with open(fpath) as fh:
+                    for row in csv.DictReader(fh):
+                        kn = row.get("Kernel_Name", "")
+                        m = re.search(r"rt_trace<(\w+), (\w+)", kn) or re.search(r"rt_traceILb([01])ELb([01])E", kn)
+                        if kernel_substr not in kn or not m or m.group(2) in ("true", "1"):     # not the trace kernel, or its counting variant
+                            continue
+                        name = row["Counter_Name"]
+                        sums[name] = sums.get(name, 0.0) + float(row["Counter_Value"])
+                        launches.setdefault(name, set()).add(row.get("Dispatch_Id"))
+            for name in counters:
+                if name not in sums:
+                    return None, "counter %s missing from rocprofv3's output" % name
+                out[name] = sums[name] / max(1, len(launches[name]))
+        except Exception as e:      # noqa: BLE001
+            return None, "rocprofv3 pass %s: %r" % (counters[0], e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)     # 0.25 s timed at N=1: start-up and the final sync (~0.8 ms) no longer show
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="h8")
-    ap.add_argument("--width", type=int, default=FRAME_W)
-    ap.add_argument("--height", type=int, default=FRAME_H)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3", help="which BASELINE config (default: the headline, configs[2])")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--strict-fp", action="store_true", help="time the no-FMA kernel variant instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic / measured FP64 come from profiles/ then)")
     args = ap.parse_args()
+    cfg_scene, cfg_w, cfg_h, single = CONFIGS[args.config]
+    scene_name = args.scene or cfg_scene
+    w, h = args.width or cfg_w, args.height or cfg_h
+    if args.config != "cfg3" and "--steps" not in sys.argv:
+        args.steps = 400 if args.config == "cfg4" else 20
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a "Hostname / Librccl path" banner
     # on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
@@ -105,6 +168,7 @@ def main():
     # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails
     # (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept here so a bare launch works too.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
     import torch
     import torch.distributed as dist
     import rt_host
@@ -121,13 +185,14 @@ def main():
     # the exchange goes over gloo through host memory.  Never a measurement (the JSON says so).
     rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
     # RT_BENCH_FORCE_EXCHANGE=1 (N=1 only): run the N>1 code path with ONE rank - RGB24 tiles, a real 1-rank RCCL
-    # all_to_all_single (a self copy), the side stream, the de-interleave.  It measures what the plan itself costs (host
+    # collective (a self copy), the side stream, the de-interleave.  It measures what the plan itself costs (host
     # issue time, copy kernels and de-interleave competing with the render) on a one-GPU box; the JSON says so.
     force = world == 1 and os.environ.get("RT_BENCH_FORCE_EXCHANGE") == "1"
     multi = world > 1 or force
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    ctl_dev = "cpu" if rehearse else dev          # where the small control tensors of the collectives live
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -136,26 +201,25 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    w, h = args.width, args.height
-    scene = rt_host.load_scene(args.scene)
+    scene = rt_host.load_scene(scene_name)
     ss = scene.get("supersample", 1)
     lib = rt_host.load_library()
     renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
     flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
 
-    # N>1: the bands cross xGMI as RGB24 (the alpha byte is the constant 255, main.js:198; the de-interleave on the
-    # receiving rank restores it) — a quarter less link time, which is what bounds N=2 and N=4.
-    # RT_BENCH_RGBA_EXCHANGE=1 ships RGBA8 instead (A/B).
-    # Which plan reassembles the frames (see below).  The all-to-all plan is always set up.  From N=6 on - where a rank's
-    # share of a frame per link is small enough for RGBA8 not to be link-bound (4.1 MB per link per step at N=8 against
-    # 12.4 MB of RGB24 at N=2) - the peer-store plan is set up as well, proves itself in a pre-flight, and then BOTH plans
-    # are timed for a few groups of steps and the faster one runs the measurement.  RT_BENCH_P2P=1 / 0 forces a plan.
+    # Which ranks end up owning whole frames: every rank (batch mode: frame f of a step on rank f) or rank 0 alone
+    # (single-frame mode: the one frame of a step).
+    owners = [0] if (single and multi) else list(range(world))
+    i_own = rank in owners
+    frames_per_step = len(owners)
+
+    # Which plan reassembles the frames (module docstring).  The exchange plan is always set up unless peer stores are forced.
     p2p_env = os.environ.get("RT_BENCH_P2P")
     if p2p_env == "auto":                                                         # set both up and calibrate, at any N
         p2p_env = None
         p2p = multi
     else:
-        p2p = multi and (p2p_env == "1" or (p2p_env is None and world >= 6))     # try to set the peer-store plan up
+        p2p = multi and (p2p_env == "1" or (p2p_env is None and (world >= 6 or (single and world > 1))))
     a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
     plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
     batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
@@ -168,12 +232,10 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    # N>1: ONE exchange serves `every` consecutive steps (RT_BENCH_EXCHANGE_EVERY, default 4): a c10d collective costs
-    # ~60-150 us of host time to issue (measured: 57 us for a 1-rank all_to_all_single), about as much as a step's GPU
-    # work, so issuing one per step would make the job host-bound; per-GPU work per STEP stays one frame's worth of
-    # pixels at every N, the bands of `every` steps travel together (larger messages also use the links better).
-    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "4"))) if multi else 1
-    frames = torch.empty((every, h, w, 4), dtype=torch.uint8, device=dev)   # the frames this rank reassembles (N=1: the frame)
+    # N>1: ONE exchange serves `every` consecutive steps (RT_BENCH_EXCHANGE_EVERY, default 4; 1 for the 1 GiB frames of cfg5)
+    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "1" if w * h >= (1 << 27) else "4"))) if multi else 1
+    # the frames this rank reassembles (N=1: the frame); ranks that own nothing keep a token allocation
+    frames = torch.empty((every, h, w, 4) if i_own else (1, 1, 1, 4), dtype=torch.uint8, device=dev)
     frame = frames[0]
     # Opt-in (RT_BENCH_TWO_STREAMS=1, N=1): consecutive frames alternate between two HIP streams and two frame
     # buffers, so the tail of frame k overlaps the head of frame k+1 (+3 % measured).  Off by default so that
@@ -183,91 +245,115 @@ def main():
     tstream_b = torch.cuda.Stream(device=dev) if two_streams else None
     whole = rt_host.RtTiles(h, 0, 1, 1)
     my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
-    # RT_BENCH_P2P=1 (opt-in, N>1): the PEER-STORE plan.  No data collective: every rank's kernel stores its tiles of frame f
-    # straight into rank f's frame buffer (peer-mapped once through IPC handles; rt_render_scatter_device), rows in frame
-    # order, RGBA8 - and one tiny all_reduce per group of steps is the barrier that says "the group's frames are whole".
-    # No send/recv buffers, no RCCL copy kernels, no de-interleave pass (the all-to-all plan's own overhead is 13 % on one
-    # GPU, RT_BENCH_FORCE_EXCHANGE).  Opt-in because a one-GPU box cannot exercise real xGMI peer stores.
     frame_bytes = w * h * 4
+    import oracle_util as ou
+
+    def reference_rows():
+        """(rows, expected bytes) to check a reassembled frame against: the rows the reference itself rendered (tests/golden) when
+        this frame size has them, else a few rows from the oracle's C restatement (checker only, untimed)."""
+        for f in ou.manifest()["frames"]:
+            if f["scene"] == scene_name and (f["w"], f["h"]) == (w, h) and f["rows"]:
+                return f["rows"], ou.golden_frame(f), "tests/golden/%s (rendered by the reference itself)" % f["file"]
+        rows = sorted(set(int((k + 0.5) * h / 5) for k in range(5)))
+        blob = rt_host.flatten_scene(scene)
+        return rows, np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8), "oracle/rt_oracle.c rows %s" % rows
+
+    check_rows, check_bytes, check_source = reference_rows()
+
+    def worst_lsb(host_frame):
+        return int(ou.max_lsb(np.ascontiguousarray(host_frame[check_rows]).reshape(-1), check_bytes)[0])
+
     p2p_note = None
+    my_buf, peer_buf = None, {}
     if p2p:
         # Set-up and PRE-FLIGHT of the peer-store plan; anything that goes wrong on any rank (no IPC, no peer access, a frame
-        # that does not match the reference's rows) makes every rank fall back to the all-to-all plan, and the JSON says so.
+        # that does not match the reference's rows) makes every rank fall back to the exchange plan, and the JSON says so.
         import ctypes as C
-        import numpy as np
-        import oracle_util as ou0
-        my_buf, peer_buf, problem = None, [], None
+        problem, mine = None, None
         try:
-            my_buf = lib.rt_alloc_device(dev_index, 2 * every * frame_bytes)      # [slot][step of the group] whole frames
-            if not my_buf:
-                raise RuntimeError("rt_alloc_device: " + lib.rt_last_error().decode())
-            hnd = C.create_string_buffer(64)
-            if lib.rt_ipc_export(dev_index, my_buf, hnd) != 0:
-                raise RuntimeError("rt_ipc_export: " + lib.rt_last_error().decode())
-            mine = hnd.raw
+            if i_own:
+                my_buf = lib.rt_alloc_device(dev_index, 2 * every * frame_bytes)      # [slot][step of the group] whole frames
+                if not my_buf:
+                    raise RuntimeError("rt_alloc_device: " + lib.rt_last_error().decode())
+                hnd = C.create_string_buffer(64)
+                if lib.rt_ipc_export(dev_index, my_buf, hnd) != 0:
+                    raise RuntimeError("rt_ipc_export: " + lib.rt_last_error().decode())
+                mine = hnd.raw
             if os.environ.get("RT_BENCH_P2P_INJECT_FAILURE") == str(rank):     # test hook for the fallback
                 raise RuntimeError("injected failure on rank %d" % rank)
         except Exception as e:      # noqa: BLE001
             problem, mine = repr(e), None
         handles = [None] * world
-        dist.all_gather_object(handles, mine)
-        if problem is None and any(x is None for x in handles):
-            problem = "another rank could not export its buffer"
+        dist.all_gather_object(handles, (problem, mine))
+        if problem is None:
+            bad = [g for g in range(world) if handles[g][0] is not None or (g in owners and handles[g][1] is None)]
+            if bad:
+                problem = "rank %d: %s" % (bad[0], handles[bad[0]][0] or "could not export its buffer")
         if problem is None:
             try:
-                for g in range(world):
+                for g in owners:
                     if g == rank:
-                        peer_buf.append(my_buf)
+                        peer_buf[g] = my_buf
                     else:
                         q = C.c_void_p()
-                        hb = C.create_string_buffer(handles[g], 64)
+                        hb = C.create_string_buffer(handles[g][1], 64)
                         if lib.rt_ipc_open(dev_index, hb, C.byref(q)) != 0:
                             raise RuntimeError("rt_ipc_open(rank %d): %s" % (g, lib.rt_last_error().decode()))
-                        peer_buf.append(q.value)
+                        peer_buf[g] = q.value
             except Exception as e:      # noqa: BLE001
                 problem = repr(e)
         oks = [None] * world
         dist.all_gather_object(oks, problem)
         if all(x is None for x in oks):
-            # pre-flight: one step through the peer stores, then every rank checks the frame it owns
-            lib.rt_memset_device(dev_index, my_buf, 0, frame_bytes)
+            # pre-flight: one step through the peer stores, then every owner checks the frame it owns
+            if i_own:
+                lib.rt_memset_device(dev_index, my_buf, 0, frame_bytes)
             dist.barrier()
-            renderer.render_scatter(w, h, list(peer_buf), my_tiles, flags=flags, want_stats=True)     # returns when the launch is done
+            renderer.render_scatter(w, h, [peer_buf[g] for g in owners], my_tiles, flags=flags, want_stats=True)     # returns when the launch is done
             dist.barrier()
             worst = 0
-            host = np.empty((h, w, 4), dtype=np.uint8)
-            lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf, frame_bytes)
-            for f in ou0.manifest()["frames"]:
-                if f["scene"] == args.scene and (f["w"], f["h"]) == (w, h) and f["rows"]:
-                    worst = max(worst, int(ou0.max_lsb(np.ascontiguousarray(host[f["rows"]]).reshape(-1), ou0.golden_frame(f))[0]))
-            if not (host[..., 3] == 255).all():
-                worst = max(worst, 255)                                # a row nobody wrote
+            if i_own:
+                host = np.empty((h, w, 4), dtype=np.uint8)
+                lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf, frame_bytes)
+                worst = worst_lsb(host)
+                if not (host[..., 3] == 255).all():
+                    worst = max(worst, 255)                                # a row nobody wrote
+                del host
             worsts = [None] * world
             dist.all_gather_object(worsts, worst)
             if max(worsts) > 1:
                 oks = ["pre-flight frame differs from the reference's rows by %d LSB" % max(worsts)]
         if not all(x is None for x in oks):
-            p2p_note = "peer-store plan not usable (%s): all-to-all plan used instead" % next(x for x in oks if x is not None)
+            p2p_note = "peer-store plan not usable (%s): exchange plan used instead" % next(x for x in oks if x is not None)
             if rank == 0:
                 print("bench.py: " + p2p_note, file=sys.stderr, flush=True)
-            for g, q in enumerate(peer_buf):
+            for g, q in peer_buf.items():
                 if g != rank:
                     lib.rt_ipc_close(dev_index, q)
+            peer_buf = {}
             dist.barrier()
             if my_buf:
                 lib.rt_free_device(dev_index, my_buf)
+                my_buf = None
             p2p = False
         else:
-            token = torch.zeros(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+            token = torch.zeros(1, dtype=torch.int32, device=ctl_dev)
     # `mode["p2p"]`: the plan the step machinery below uses right now (the calibration switches it back and forth)
     mode = {"p2p": p2p}
-    if multi and not (p2p and p2p_env == "1"):
-        # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
-        send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-        host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
-    pending = []      # (work, slot, steps in it) of exchanges in flight; at most 2
-    group = {"slot": 0, "fill": 0}                                 # the exchange buffer being filled, and how many steps are in it
+    have_exchange = multi and not (p2p and p2p_env == "1")
+    if have_exchange:
+        if not single:
+            # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
+            send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+            recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+            host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
+        else:
+            # [step of the group][band] on every rank; rank 0 gathers [source rank][step][band]
+            send = [torch.empty((every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+            recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) if i_own else None for _ in range(2)]
+            host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if (rehearse and i_own) else None
+    pending = []      # (work, slot, steps in it, plan) of exchanges in flight; at most 2
+    group = {"slot": 0, "fill": 0, "last_slot": 0}                 # the exchange buffer being filled, and how many steps are in it
     # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
     # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
     side = torch.cuda.Stream(device=dev) if multi else None
@@ -276,21 +362,23 @@ def main():
     def render_step(slot, j=0):
         if not multi:
             renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
-        elif mode["p2p"]:   # frame f of this step -> rank f's buffer, slot `slot`, position j; rows in frame order
+        elif mode["p2p"]:   # frame of owner o in this step -> o's buffer, slot `slot`, position j; rows in frame order
             off = (slot * every + j) * frame_bytes
-            renderer.render_scatter(w, h, [b + off for b in peer_buf], my_tiles, stream=stream, flags=flags)
-        else:   # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
+            renderer.render_scatter(w, h, [peer_buf[g] + off for g in owners], my_tiles, stream=stream, flags=flags)
+        elif not single:    # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
             renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
+        else:               # this rank's tiles of the step's one frame -> send[slot][j]
+            renderer.render_batch(w, h, send[slot][j].data_ptr(), my_tiles, 1, 0, stream=stream, flags=batch_flags)
 
     def finish(item):
         work, slot, count, was_p2p = item
         with torch.cuda.stream(side):
             work.wait()                                          # the side stream waits for the exchange (p2p: the barrier)
-            if was_p2p:
-                count = 0                                        # the frames are already whole, in place
+            if was_p2p or not i_own:
+                count = 0                                        # the frames are already whole, in place (or live elsewhere)
             elif rehearse:
                 recv[slot].copy_(host_recv)
-            for j in range(count):                               # one whole frame per step of the group ends up on this rank
+            for j in range(count):                               # one whole frame per step of the group ends up on an owner
                 shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
             slot_free[slot].record(side)
         tstream.wait_event(slot_free[slot])                      # ordering only: that work is two groups old by the time it matters
@@ -301,10 +389,12 @@ def main():
             if rehearse:
                 torch.cuda.synchronize()                          # gloo knows nothing of the GPU: finish the stores first
             work = dist.all_reduce(token, async_op=True)          # after every rank's stores of this group (stream order)
+        elif not single:
+            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True) if rehearse else shard.exchange_bands(send[slot], recv[slot], async_op=True)
         elif rehearse:
-            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True)
+            work = shard.gather_bands(send[slot].cpu(), host_recv, dst=0, async_op=True)
         else:
-            work = shard.exchange_bands(send[slot], recv[slot], async_op=True)
+            work = shard.gather_bands(send[slot], recv[slot], dst=0, async_op=True)
         pending.append((work, slot, group["fill"], mode["p2p"]))   # overlaps with the renders of the next group
         group["last_slot"] = slot
         group["slot"], group["fill"] = slot ^ 1, 0
@@ -341,7 +431,7 @@ def main():
     drain()
     fence()
 
-    # Both plans are set up (N >= 6, nothing forced): time a few groups of steps with each and keep the faster one.  The
+    # Both plans are set up (nothing forced): time a few groups of steps with each and keep the faster one.  The
     # slower rank decides (MAX over ranks), so every rank makes the same choice.
     calibration = None
     if multi and p2p and p2p_env is None:
@@ -352,16 +442,47 @@ def main():
                 step(k)
             drain()
             torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearse else dev)
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         calibration = {}
-        for name, flag in (("all_to_all", False), ("peer_stores", True)):
+        n_cal = max(every, min(8 * every, int(0.25 / max(1e-4, w * h / 6e10 / max(1, world if single else 1)))))   # ~0.25 s per plan at most
+        for name, flag in (("exchange", False), ("peer_stores", True)):
             mode["p2p"] = flag
             timed(every)                                   # this plan's own first-use costs
-            calibration[name] = round(timed(8 * every) / (8 * every) * 1e3, 4)      # ms per step
-        mode["p2p"] = calibration["peer_stores"] <= calibration["all_to_all"]
+            calibration[name] = round(timed(n_cal) / n_cal * 1e3, 4)      # ms per step
+        mode["p2p"] = calibration["peer_stores"] <= calibration["exchange"]
         fence()
+
+    # ---- steady clocks first: trains of launches until two consecutive trains agree within 1 % and at least 50 ms have passed
+    #      (a GPU that has just been idle runs its first milliseconds below its sustained clock: a 5-step warm-up followed
+    #      by 20 timed steps would measure that transient, not the kernel) ----
+    settle = {"trains": 0, "ms": 0.0, "last_two_ms_per_step": None}
+    if os.environ.get("RT_BENCH_NO_SETTLE") != "1":
+        n_train = max(every, min(64, int(0.01 / max(1e-5, w * h / 6e10)) or 1))       # ~10 ms of launches per train
+        n_train = (n_train + every - 1) // every * every
+        prev, t_begin = None, time.perf_counter()
+        for _ in range(40):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n_train):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            cur = (time.perf_counter() - t0) / n_train
+            settle["trains"] += 1
+            stop = prev is not None and abs(cur - prev) <= 0.01 * prev and (time.perf_counter() - t_begin) >= 0.05
+            settle["last_two_ms_per_step"] = [round(1e3 * x, 4) for x in (prev if prev is not None else cur, cur)]
+            prev = cur
+            if multi:                                            # every rank must leave the loop together
+                tt = torch.tensor([0 if stop else 1], dtype=torch.int32, device=ctl_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                stop = int(tt.item()) == 0
+            if stop:
+                break
+        settle["ms"] = round(1e3 * (time.perf_counter() - t_begin), 1)
+        fence()
+
     for k in range(args.warmup):
         step(k)
     drain()
@@ -373,18 +494,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     channels = 4 if (not multi or mode["p2p"]) else a2a_channels          # bytes per pixel the chosen plan's launches store
     # ---- dominant kernel: average launch duration, HIP events on the launch stream.  At N=1 the timed region IS a train of
-    #      these launches on this stream, so two events around the region give the average over every launch of it (what
+    #      these launches on this stream, so two events around a train of them give the average over every launch (what
     #      rocprofv3's per-kernel average of the same command shows); at N>1 the region also waits for slots, so the kernel is
-    #      timed on a train of its own right after ----
+    #      timed on a train of its own ----
     fence()
-    n_train = args.steps if not multi else min(args.steps, 200)
+    n_train = max(20, min(args.steps, 2000)) if not multi else min(max(20, args.steps), 200)
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(min(10, n_train)):
         render_step(0)
@@ -394,21 +515,19 @@ def main():
     ev_b.record()
     torch.cuda.synchronize()
     kernel_ms = ev_a.elapsed_time(ev_b) / n_train
-    launch_pixels = w * h if not multi else world * plan.pixels_of(rank)
+    launch_pixels = w * h if not multi else frames_per_step * plan.pixels_of(rank)
 
-    # one more (untimed) step; EVERY rank checks the frame it reassembled against the rows the reference itself
-    # rendered (tests/golden, fixtures - not the oracle), and the worst rank is reported
+    # one more (untimed) group of steps; EVERY owner checks the frames it reassembled against the rows the reference itself
+    # rendered (tests/golden, fixtures) or, for a frame size without fixtures, a few rows of the C restatement
     fence()
     frames.zero_()
-    if p2p and lib.rt_memset_device(dev_index, my_buf, 0, 2 * every * frame_bytes) != 0:
+    if p2p and i_own and lib.rt_memset_device(dev_index, my_buf, 0, 2 * every * frame_bytes) != 0:
         raise SystemExit("bench.py: rt_memset_device: " + lib.rt_last_error().decode())
     fence()                                                        # nobody stores into a buffer that is still being cleared
     for k in range(every):                                         # one whole group, so every frame slot is rewritten
         step(k)
     drain()
     fence()
-    import numpy as np
-    import oracle_util as ou
 
     def reassembled(j):
         if not mode["p2p"]:
@@ -418,45 +537,69 @@ def main():
             raise SystemExit("bench.py: rt_copy_to_host: " + lib.rt_last_error().decode())
         return host
 
-    max_lsb = None
-    for f in ou.manifest()["frames"]:
-        if f["scene"] == args.scene and (f["w"], f["h"]) == (w, h) and f["rows"]:
-            for j in range(every):
-                got = np.ascontiguousarray(reassembled(j)[f["rows"]]).reshape(-1)
-                max_lsb = max(max_lsb or 0, ou.max_lsb(got, ou.golden_frame(f))[0])
-    if world > 1 and max_lsb is not None:
-        t = torch.tensor([int(max_lsb)], dtype=torch.int64, device="cpu" if rehearse else dev)
+    max_lsb = 0
+    if i_own:
+        for j in range(every):
+            fr = reassembled(j)
+            max_lsb = max(max_lsb, worst_lsb(fr))
+            if not (fr[..., 3] == 255).all():
+                max_lsb = 255                                          # a row nobody wrote
+            del fr
+    if world > 1:
+        t = torch.tensor([int(max_lsb)], dtype=torch.int64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         max_lsb = int(t.item())
-    parity_ok = max_lsb is None or max_lsb <= 1          # tolerance: 1 LSB per channel
+    parity_ok = max_lsb <= 1          # tolerance: 1 LSB per channel
     if rank == 0:
         # work counters from the instrumented variant (untimed)
-        st = renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
+        cnt_frame = frame if i_own and frames.shape[1] == h else torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+        st = renderer.render_tiles(w, h, cnt_frame.data_ptr(), whole, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
         rays_pp, shadow_pp, tests_pp = st.rays / st.pixels, st.shadow_rays / st.pixels, st.sphere_tests / st.pixels
-        frames_per_step = world
         total_pixels = w * h * frames_per_step * args.steps
         value = total_pixels / elapsed / 1e6
         flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
         algo_bytes = float(channels) * launch_pixels        # what one launch stores: RGBA8, or RGB24 bands at N>1
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            tj = json.load(open(tpath))
-            key = "%s_%dx%d" % (args.scene, w, h)
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
+        # HBM traffic and executed FP64 instructions per launch: PMC passes over a short child run of this same command
+        traffic, traffic_src, fp64_measured = None, None, None
+        pmc, pmc_note = (None, "not collected (--no-pmc)") if (args.no_pmc or multi or os.environ.get("RT_BENCH_CHILD") == "1") else pmc_passes(
+            ["--config", args.config] + (["--scene", scene_name] if args.scene else [])
+            + (["--width", str(w)] if args.width else []) + (["--height", str(h)] if args.height else []) + (["--strict-fp"] if args.strict_fp else []))
+        if pmc:
+            traffic = pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0          # KiB -> bytes; FETCH_SIZE counts half (MI355X_MICROARCH.md, HBM)
+            traffic_src = "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) over a 12-step child run of this command; FETCH_SIZE doubled (gfx950)"
+            fl = (2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] + pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"]) * 64.0
+            fp64_measured = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "salu_insts_per_launch": pmc["SQ_INSTS_SALU"],
+                             "fma_f64": pmc["SQ_INSTS_VALU_FMA_F64"], "add_f64": pmc["SQ_INSTS_VALU_ADD_F64"], "mul_f64": pmc["SQ_INSTS_VALU_MUL_F64"],
+                             "trans_f64": pmc["SQ_INSTS_VALU_TRANS_F64"], "flop_per_launch_upper_bound": fl,
+                             "achieved": round(fl / (kernel_ms * 1e-3) / 1e12, 3), "frac": round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
+                             "note": "wave-instructions x 64 lanes (an upper bound: assumes a full exec mask), FMA = 2 flop; this run's counters, this run's kernel_ms"}
+        else:
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            key = "%s_%dx%d" % (scene_name, w, h)
+            if os.path.exists(tpath) and world == 1:
+                tj = json.load(open(tpath))
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+                    traffic_src = "REPLAYED from profiles/traffic.json (%s): %s" % (tj[key].get("source", "committed profile"), pmc_note)
+                    if "fp64" in tj[key]:
+                        fl = tj[key]["fp64"]["flop_per_launch_upper_bound"]
+                        fp64_measured = dict(tj[key]["fp64"], achieved=round(fl / (kernel_ms * 1e-3) / 1e12, 3),
+                                             frac=round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
+                                             note="counters REPLAYED from profiles/traffic.json, this run's kernel_ms")
         if not multi:
             how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
         elif mode["p2p"]:
-            how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
+            how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
                    "frame buffer of the rank that owns each frame (peer-mapped over xGMI, RGBA8, rows in place): no data collective, no "
-                   "de-interleave; one all_reduce per %d steps is the barrier" % (world, TILE_ROWS, world, every))
+                   "de-interleave; one all_reduce per %d steps is the barrier"
+                   % ("ONE frame, whole on rank 0" if single else "a batch of %d frames" % world, TILE_ROWS, world, every))
         else:
-            how = ("a step = a batch of %d frames: interleaved %d-row tiles over %d ranks, one launch per rank, ONE all-to-all (RCCL over xGMI) "
-                   "reassembles frame f on rank f (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
+            how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank, ONE %s (RCCL over xGMI) "
+                   "reassembles %s (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
                    "collective, which overlaps the renders of the next %d steps"
-                   % (world, TILE_ROWS, world, "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
+                   % ("ONE frame" if single else "a batch of %d frames" % world, TILE_ROWS, world, "gather to rank 0" if single else "all-to-all",
+                      "the frame on rank 0" if single else "frame f on rank f", "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
         # the store roofline as this box delivers it (quote a measured fill next to the nominal peak): a 2 GiB
         # torch fill, best of 5, on the launch stream
         fill_gbs = None
@@ -476,24 +619,31 @@ def main():
                 del big
             except Exception:      # noqa: BLE001  (a small box: the nominal peak stands alone)
                 fill_gbs = None
+        model_tf = flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; %s" % (
-                args.scene, len(scene["objects"]), len(scene["lights"]), scene["segs"], ss, w, h, how),
-                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step, "pixels_per_gpu_per_step": w * h,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (single and multi) else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; %s" % (
+                args.config if (scene_name, w, h) == CONFIGS[args.config][:3] else "custom", scene_name, len(scene["objects"]), len(scene["lights"]),
+                scene["segs"], ss, w, h, how),
+                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step,
+                "pixels_per_gpu_per_step": (w * h * frames_per_step) // world if multi else w * h,
+                "steady_state_warmup": settle,
                 **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {}),
-                **({"FORCED_EXCHANGE": "the N>1 plan run by ONE rank (1-rank RCCL all-to-all = self copy): the plan's own overhead, not the headline"} if force else {})},
+                **({"FORCED_EXCHANGE": "the N>1 plan run by ONE rank (1-rank RCCL collective = self copy): the plan's own overhead, not the headline"} if force else {})},
             "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
             "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
-            "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok,
+            "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok, "parity_checked_against": check_source,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "measured_fill_GBs": fill_gbs, "frac_of_measured_fill": (round(achieved / fill_gbs, 6) if fill_gbs else None),
                          "note": "%d B per output pixel (one %s store); the path is FP64-VALU bound, see fp64_valu" % (channels, "RGBA8" if channels == 4 else "RGB24")},
-            "fp64_valu": {"flop_per_pixel_model": round(flops_pp, 1), "achieved": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12, 3),
-                          "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
+            "fp64_valu": {"peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "measured": fp64_measured,
+                          "model": {"flop_per_pixel": round(flops_pp, 1), "achieved": round(model_tf, 3), "frac": round(model_tf / FP64_VALU_PEAK_TF, 4),
+                                    "note": "the REFERENCE's algorithmic operation count (SURVEY 8(d): 15/test + 120/ray + 60/shadow ray) over this kernel's time; the "
+                                            "product kernel executes fewer operations than that (anchored tests are 4, not 10), so this is a rate of useful work, not of executed flops"},
                           "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
         }
         if p2p_note:
@@ -502,14 +652,15 @@ def main():
             out["config"]["plan_calibration_ms_per_step"] = calibration
         if multi and mode["p2p"]:
             out["exchange"] = {"plan": "peer stores (rt_render_scatter_device through IPC-mapped frame buffers)", "collective": "all_reduce of one int per group (barrier)",
-                               "bytes_stored_remotely_per_rank_per_step": (world - 1) * plan.pixels_of(rank) * 4, "steps_per_barrier": every}
+                               "bytes_stored_remotely_per_rank_per_step": sum(1 for g in owners if g != rank) * plan.pixels_of(rank) * 4, "steps_per_barrier": every}
         elif multi:
-            out["exchange"] = {"collective": "all_to_all_single", "bytes_sent_per_rank_per_step": (world - 1) * plan.band_bytes,
+            out["exchange"] = {"plan": "exchange", "collective": "gather to rank 0" if single else "all_to_all_single",
+                               "bytes_sent_per_rank_per_step": plan.band_bytes if single else (world - 1) * plan.band_bytes,
                                "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
                                "steps_per_collective": every}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.scene, w, h)
+                out["cpu_baseline"] = cpu_baseline(scene_name, w, h)
             except Exception as e:   # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -517,11 +668,12 @@ def main():
     renderer.close()
     if p2p:
         fence()
-        for g in range(world):
+        for g, q in peer_buf.items():
             if g != rank:
-                lib.rt_ipc_close(dev_index, peer_buf[g])
+                lib.rt_ipc_close(dev_index, q)
         fence()
-        lib.rt_free_device(dev_index, my_buf)
+        if my_buf:
+            lib.rt_free_device(dev_index, my_buf)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

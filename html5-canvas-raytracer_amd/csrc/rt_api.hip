@@ -57,8 +57,9 @@ struct device_state {
   unsigned long long *d_counters = nullptr;
   void *d_frame = nullptr;               // rt_render scratch: this device's tiles (or the whole frame)
   size_t frame_bytes = 0;
-  void *d_gather = nullptr;              // device 0 only: gather target
+  void *d_gather = nullptr;              // device 0 only: gather target (fallback plan of rt_render on several GPUs)
   size_t gather_bytes = 0;
+  int peer_to_root = 0;                  // rt_render on several GPUs: 1 = this device may store into device 0's memory, -1 = it may not, 0 = not asked yet
   // rt_render: the scene of the previous call stays resident; a call with the same blob (byte for byte) reuses it
   // (upload + table builds cost 0.1 ms for 8 spheres and 1.8 ms for 64, against a 0.7 ms frame)
   struct rt_scene_dev *cached_scene = nullptr;
@@ -114,11 +115,26 @@ struct rt_scene_dev {
   unsigned lds_bytes;
   double lights[RT_MAX_LIGHTS][3];   // host copy: lights travel in the kernarg segment
   uint32_t enclosing;            // sphere that strictly contains everything else (a skybox), or ~0u
+  // cost-ordered dispatch (dispatch_order below): per sphere its screen rectangle (X/D, Y/D bounds, scene order) and a weight,
+  // and the order tables built so far, one per (frame size, tile set), kept on the device
+  std::vector<rt_geom> host_cull;
+  std::vector<uint32_t> tile_weight;
+  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked; uint32_t *d_order; };
+  std::vector<order_entry> orders;
+  std::mutex order_mu;
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
 };
 
 // ------------------------------------------------------------------------------------ lifetime
 extern "C" uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" const char *rt_build_id(void) { return RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION; }
+
+// main.js:204-205: 'build #' + build + ' (' + elapsed + 'ms)', elapsed a whole number of milliseconds (Date.now() difference)
+extern "C" int rt_elapsed_report(const rt_stats *stats, char *out, size_t cap) {
+  if (!stats || (!out && cap)) return fail(RT_ERR_INVALID, "rt_elapsed_report: NULL argument");
+  const double ms = (stats->total_ms >= 0.0 && stats->total_ms < 1e15) ? stats->total_ms : 0.0;
+  return snprintf(out, cap, "build #%s (%lldms)", rt_build_id(), (long long)llround(ms));
+}
 extern "C" const char *rt_last_error(void) { return g_err; }
 
 extern "C" int rt_init(int max_devices) {
@@ -163,7 +179,7 @@ extern "C" int rt_scene_validate(const void *blob, size_t bytes) {
   if (hd->n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_INVALID, "n_lights %u > %u", hd->n_lights, RT_MAX_LIGHTS);
   if (hd->n_textures > RT_MAX_TEXTURES) return fail(RT_ERR_INVALID, "n_textures %u > %u", hd->n_textures, RT_MAX_TEXTURES);
   if (hd->segs > RT_MAX_SEGS) return fail(RT_ERR_INVALID, "segs %u > %u", hd->segs, RT_MAX_SEGS);
-  if (hd->supersample != 1 && hd->supersample != 2) return fail(RT_ERR_INVALID, "supersample must be 1 or 2");
+  if (hd->supersample < 1 || hd->supersample > 4) return fail(RT_ERR_INVALID, "supersample must be 1, 2, 3 or 4");
   if (!(hd->fov_deg > 0.0 && hd->fov_deg < 180.0)) return fail(RT_ERR_INVALID, "fov_deg must be in (0,180)");
   auto in_range = [&](uint64_t off, uint64_t len) { return (off & 7u) == 0 && off >= sizeof(rt_scene_header) && off <= bytes && len <= bytes - off; };
   if (!in_range(hd->objects_offset, (uint64_t)hd->n_objects * sizeof(rt_sphere))) return fail(RT_ERR_INVALID, "object table out of bounds");
@@ -456,6 +472,19 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     for (uint32_t j = 0; j < hd->n_objects && ok; j++) if (j != e) ok = dist_to(ob[j].origin) + sqrt(ob[j].r2) < lim;
     if (ok && hd->n_objects > 1) s->enclosing = e;
   }
+  // cost-ordered dispatch: what a tile that shows sphere j is expected to cost, in rough units of one shaded hit - a guess
+  // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
+  // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
+  s->host_cull.resize(hd->n_objects);
+  s->tile_weight.resize(hd->n_objects);
+  for (uint32_t i = 0; i < hd->n_objects; i++) {
+    s->host_cull[i] = cull_rect(hd, ob[i]);
+    const bool lit = ob[i].albedo[1] > 0.0 || ob[i].albedo[2] > 0.0, refl = ob[i].albedo[3] > 0.0, refr = ob[i].albedo[4] > 0.0;
+    const uint32_t depth = hd->segs > 1 ? (hd->segs - 1 < 4 ? hd->segs - 1 : 4) : 0;
+    uint32_t wgt = (lit ? 2u : 0u) + ((refl || refr) ? 3u * depth : 0u);
+    if (refl && refr && hd->segs > 1) wgt += 8u * (1u << (hd->segs - 1 < 5 ? hd->segs - 1 : 5));
+    s->tile_weight[i] = wgt;
+  }
   // device copy of the blob: the `reserved` slot of each sphere record carries 1/r for the product kernel
   std::vector<uint8_t> patched((const uint8_t *)blob, (const uint8_t *)blob + bytes);
   {
@@ -552,6 +581,7 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (s->d_lds_image) (void)hipFree(s->d_lds_image);
   if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
   if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
+  for (const rt_scene_dev::order_entry &e : s->orders) (void)hipFree(e.d_order);
   delete s;
 }
 
@@ -563,7 +593,7 @@ extern "C" int rt_render_tiles_device(rt_scene_dev *s, uint32_t w, uint32_t h, c
 
 namespace {
 int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
-                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats);
+                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats, uint32_t ss_override = 0u);
 #ifdef RT_TESTING
 thread_local struct { double *d_buf; uint32_t x, y; } g_probe = {nullptr, 0u, 0u};
 #endif
@@ -612,8 +642,206 @@ extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h,
 }
 
 namespace {
+// The product kernel's launch table, and cost-ordered dispatch.  The product kernel runs on a FLAT grid and reads, per workgroup,
+// one 8-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band} (rt_kernel.hip:
+// rt_pixel_of) - the tile / row-block arithmetic of the plain grid done once on the host.  That also puts the ORDER in which
+// the hardware hands the tiles out in the host's hands.  In grid order a frame ends on whatever lies at the bottom right -
+// for the reference's scenes the floor and the sphere that both reflects and refracts, the dearest tiles of all - and the
+// last of them run alone on an otherwise idle chip.  For launches of many workgroups the host therefore ranks the tiles by a
+// cost estimate (the weights of the spheres whose screen rectangle - the primary-ray cull's - touches the tile) and lists
+// them dearest first, so the launch ends on sky.  Every tile is still rendered exactly once by exactly one workgroup: the
+// picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
+const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
+                           double proj_w, double proj_h, double proj_d, bool ranked) {
+  const uint32_t ny = tiles->n_tiles * rb_per_tile;
+  const uint64_t n64 = (uint64_t)tiles_x * ny;
+  if (tiles_x > 2048u || n64 >= (1ull << 31)) { fail(RT_ERR_INVALID, "launch of %llu workgroups is beyond the launch table", (unsigned long long)n64); return nullptr; }
+  const uint32_t n = (uint32_t)n64;
+  std::lock_guard<std::mutex> lk(s->order_mu);
+  for (const rt_scene_dev::order_entry &e : s->orders)
+    if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked)
+      return e.d_order;
+  const uint32_t rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                                // output rows a workgroup covers
+  const uint32_t wg_w = RT_TILE_W * ss, wg_h = rows_per_wg * ss;                        // ... and samples
+  // small launches have no tail worth ranking; the COUNT variant and the A/B switch keep the grid's order as well
+  const bool rank = ranked && n >= 4096u;
+  std::vector<uint32_t> cost;
+  uint32_t cmax = 1;
+  if (rank) {
+    // per-tile cost: every sphere's rectangle, in sample coordinates, rasterised onto the workgroup grid
+    cost.assign(n, 1u);
+    const double W = (double)w * ss, H = (double)h * ss;
+    for (size_t j = 0; j < s->host_cull.size(); j++) {
+      const uint32_t wgt = s->tile_weight[j];
+      if (!wgt) continue;
+      const rt_geom &r = s->host_cull[j];                    // {x_lo, x_hi, y_lo, y_hi} in units of 1/D; X = sx - W/2 + 0.5, Y = H/2 - sy - 0.5
+      const double sx0 = r.ox * proj_d + proj_w - 0.5, sx1 = r.oy * proj_d + proj_w - 0.5;
+      const double sy0 = proj_h - 0.5 - r.r2 * proj_d, sy1 = proj_h - 0.5 - r.oz * proj_d;        // y grows downwards
+      if (!(sx1 >= 0.0) || !(sx0 <= W) || !(sy1 >= 0.0) || !(sy0 <= H)) continue;            // off screen
+      const uint32_t tx0 = (uint32_t)(fmax(sx0, 0.0) / wg_w), tx1 = (uint32_t)fmin(fmin(sx1, W - 1.0) / wg_w, (double)(tiles_x - 1u));
+      const double ys0 = fmax(sy0, 0.0), ys1 = fmin(sy1, H - 1.0);
+      for (uint32_t y = 0; y < ny; y++) {
+        const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
+        const double row0 = ((double)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + (double)rb * rows_per_wg) * ss;   // first sample row
+        if (row0 + wg_h <= ys0 || row0 > ys1) continue;
+        for (uint32_t x = tx0; x <= tx1 && x < tiles_x; x++) cost[(size_t)y * tiles_x + x] += wgt;
+      }
+    }
+    for (uint32_t c : cost) cmax = c > cmax ? c : cmax;
+  }
+  // counting sort, dearest first; equal costs keep the grid's order (neighbours stay neighbours)
+  std::vector<uint32_t> start(cmax + 2u, 0u);
+  if (rank) {
+    for (uint32_t c : cost) start[cmax - c + 1u]++;
+    for (uint32_t c = 0; c <= cmax; c++) start[c + 1u] += start[c];
+  }
+  std::vector<uint32_t> table((size_t)n * 2u);
+  uint32_t next = 0;
+  for (uint32_t y = 0; y < ny; y++) {
+    const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
+    const uint32_t trow0 = rb * rows_per_wg;                                             // first row of the block inside its tile
+    const uint64_t frow0 = (uint64_t)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + trow0;
+    uint32_t rows_valid = 0;
+    if (trow0 < tiles->tile_rows && frow0 < h) {
+      rows_valid = rows_per_wg;
+      if (tiles->tile_rows - trow0 < rows_valid) rows_valid = tiles->tile_rows - trow0;
+      if (h - frow0 < rows_valid) rows_valid = (uint32_t)(h - frow0);
+    }
+    const uint32_t w0 = (rows_valid << 11) | ((uint32_t)(frow0 < h ? frow0 : 0u) << 15);        // frow0 < 65536 + 8: 17 bits
+    const uint32_t w1 = tile_i * tiles->tile_rows + trow0;
+    for (uint32_t x = 0; x < tiles_x; x++) {
+      const uint32_t at = rank ? start[cmax - cost[(size_t)y * tiles_x + x]]++ : next++;
+      table[2u * (size_t)at] = w0 | x; table[2u * (size_t)at + 1u] = w1;
+    }
+  }
+  uint32_t *d = nullptr;
+  hipError_t e = hipMalloc((void **)&d, (size_t)n * 8u);
+  if (e == hipSuccess) e = hipMemcpy(d, table.data(), (size_t)n * 8u, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (d) (void)hipFree(d); fail(RT_ERR_DEVICE, "launch table: %s", hipGetErrorString(e)); return nullptr; }
+  if (s->orders.size() >= 8u) {                        // the oldest table may still be read by a launch in flight: drain the device first
+    (void)hipDeviceSynchronize();
+    (void)hipFree(s->orders.front().d_order);
+    s->orders.erase(s->orders.begin());
+  }
+  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, d});
+  return d;
+}
+
+// k x k box filter of the two-pass supersampling (k = 3, 4): `src` holds the rendered SAMPLES of this call's tiles as a band
+// (rows of k*w RGBA8 samples, k sample rows per output row, tiles contiguous), the output pixel is (sum + k*k/2) / (k*k) per
+// channel, alpha 255, stored where the trace kernel would have stored it: in the band (`out`, frame f at f*frame_stride) or,
+// scatter mode, at its row of the whole frame out_frames[f].  One work-item per output pixel; rows walked by grid y.
+struct rt_box_launch {
+  const uint32_t *src; uint64_t src_frame_stride;      // in samples (words)
+  uint32_t *out; uint64_t frame_stride; uint32_t *out_frames[RT_MAX_SCATTER]; uint32_t scatter;
+  uint32_t w, h, band_rows, tile_rows, tile_first, tile_stride;
+};
+template <uint32_t K>
+__global__ void __launch_bounds__(256) rt_box_filter_kernel(const rt_box_launch B) {
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x, f = blockIdx.z;
+  if (x >= B.w) return;
+  const uint32_t *__restrict__ src = B.src + (size_t)f * B.src_frame_stride;
+  for (uint32_t lrow = blockIdx.y; lrow < B.band_rows; lrow += gridDim.y) {
+    const uint32_t tile_i = lrow / B.tile_rows, trow = lrow - tile_i * B.tile_rows;
+    const uint32_t frow = (B.tile_first + tile_i * B.tile_stride) * B.tile_rows + trow;
+    if (frow >= B.h) continue;
+    uint32_t r = 0, g = 0, b = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < K; j++) {
+      const uint32_t *__restrict__ p = src + ((size_t)lrow * K + j) * ((size_t)B.w * K) + (size_t)x * K;
+#pragma unroll
+      for (uint32_t i = 0; i < K; i++) { const uint32_t v = p[i]; r += v & 255u; g += (v >> 8) & 255u; b += (v >> 16) & 255u; }
+    }
+    const uint32_t px = ((r + K * K / 2u) / (K * K)) | (((g + K * K / 2u) / (K * K)) << 8) | (((b + K * K / 2u) / (K * K)) << 16) | 0xff000000u;
+    if (B.scatter) B.out_frames[f][(size_t)frow * B.w + x] = px;
+    else B.out[(size_t)f * B.frame_stride + (size_t)lrow * B.w + x] = px;
+  }
+}
+
+// supersample 3 and 4: the k*w x k*h sample frame of this call's tiles is rendered by the ordinary launch
+// (supersample 1 on the sample grid: same kernels, same centre-row/column rule, same tiles with k times the rows) into
+// stream-ordered scratch memory, in pieces of at most ~512 MiB, and box-filtered into the caller's output.
+int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
+                        void *const *d_frames, hipStream_t stream, uint32_t flags, rt_stats *stats) {
+  if (flags & RT_FLAG_RGB24) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 needs supersample 1 or 2 (the %ux%u box filter stores RGBA8)", k, k);
+  if ((uint64_t)w * k > 65536u || (uint64_t)h * k > 65536u) return fail(RT_ERR_INVALID, "supersample %u: the %llu x %llu sample grid exceeds 65536", k, (unsigned long long)w * k, (unsigned long long)h * k);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const size_t row_bytes = (size_t)w * k * 4u * k;                      // the k sample rows of one output row
+  const size_t budget = (size_t)512u << 20;
+  // pieces: whole tiles while they fit, else (one tile per call, starting on a multiple of the piece height) row pieces of a tile
+  uint32_t tiles_per_piece = (uint32_t)(budget / (row_bytes * tiles->tile_rows * (size_t)n_frames));
+  uint32_t piece_rows = tiles->tile_rows;
+  if (tiles_per_piece == 0) {
+    tiles_per_piece = 1;
+    piece_rows = (uint32_t)(budget / (row_bytes * n_frames)) / RT_TILE_H * RT_TILE_H;
+    if (piece_rows == 0) piece_rows = RT_TILE_H;
+    if (piece_rows >= tiles->tile_rows) piece_rows = tiles->tile_rows;
+    else if (tiles->n_tiles != 1 || ((uint64_t)tiles->tile_first * tiles->tile_rows) % piece_rows != 0)
+      return fail(RT_ERR_NOMEM, "supersample %u: a tile of %u rows needs more than 512 MiB of sample scratch; render smaller tiles", k, tiles->tile_rows);
+  }
+  rt_stats agg;
+  memset(&agg, 0, sizeof agg);
+  for (uint32_t t0 = 0; t0 < tiles->n_tiles; t0 += tiles_per_piece) {
+    const uint32_t nt = (tiles->n_tiles - t0 < tiles_per_piece) ? tiles->n_tiles - t0 : tiles_per_piece;
+    for (uint32_t r0 = 0; r0 < tiles->tile_rows; r0 += piece_rows) {
+      // this piece as a tile set of the OUTPUT frame ...
+      rt_tiles po;
+      if (piece_rows == tiles->tile_rows) po = rt_tiles{tiles->tile_rows, tiles->tile_first + t0 * tiles->tile_stride, tiles->tile_stride, nt};
+      else po = rt_tiles{piece_rows, (uint32_t)(((uint64_t)tiles->tile_first * tiles->tile_rows + r0) / piece_rows), 1u, 1u};
+      if ((uint64_t)po.tile_first * po.tile_rows >= h) continue;
+      // ... and of the sample frame
+      const rt_tiles ps = {po.tile_rows * k, po.tile_first, po.tile_stride, po.n_tiles};
+      const uint32_t band_rows = po.n_tiles * po.tile_rows;
+      const size_t frame_words = (size_t)band_rows * k * w * k;
+      void *scratch = nullptr;
+      bool pooled = true;
+      hipError_t e = hipMallocAsync(&scratch, frame_words * 4u * n_frames, stream);
+      if (e != hipSuccess) { (void)hipGetLastError(); pooled = false; e = hipMalloc(&scratch, frame_words * 4u * n_frames); }
+      if (e != hipSuccess) return fail(RT_ERR_NOMEM, "supersample scratch (%zu bytes): %s", frame_words * 4u * n_frames, hipGetErrorString(e));
+#ifdef RT_TESTING
+      (void)hipMemsetAsync(scratch, 0xA5, frame_words * 4u * n_frames, stream);      // test build: a sample nobody writes shows up as 0xA5, not as stale data
+#endif
+      rt_stats st;
+      int rc = render_batch_impl(s, w * k, h * k, &ps, n_frames, scratch, frame_words * 4u, nullptr, stream, flags, stats ? &st : nullptr, 1u);
+      if (!rc) {
+        rt_box_launch B;
+        memset(&B, 0, sizeof B);
+        B.src = (const uint32_t *)scratch; B.src_frame_stride = frame_words;
+        B.w = w; B.h = h; B.band_rows = band_rows; B.tile_rows = po.tile_rows; B.tile_first = po.tile_first; B.tile_stride = po.tile_stride;
+        const size_t out_row0 = (size_t)t0 * tiles->tile_rows + r0;            // this piece's first row in the caller's band
+        B.out = d_out ? (uint32_t *)d_out + out_row0 * w : nullptr; B.frame_stride = frame_stride_bytes / 4u;
+        B.scatter = d_frames ? 1u : 0u;
+        if (d_frames) for (uint32_t f = 0; f < n_frames; f++) B.out_frames[f] = (uint32_t *)d_frames[f];
+        const dim3 grid((w + 255u) / 256u, band_rows < 65535u ? band_rows : 65535u, n_frames), block(256);
+        if (k == 3u) hipLaunchKernelGGL(rt_box_filter_kernel<3u>, grid, block, 0, stream, B);
+        else hipLaunchKernelGGL(rt_box_filter_kernel<4u>, grid, block, 0, stream, B);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "box filter launch: %s", hipGetErrorString(e));
+      }
+      if (pooled) e = hipFreeAsync(scratch, stream);
+      else { (void)hipStreamSynchronize(stream); e = hipFree(scratch); }
+      if (rc) return rc;
+      if (e != hipSuccess) return fail(RT_ERR_DEVICE, "supersample scratch release: %s", hipGetErrorString(e));
+      if (stats) { agg.kernel_ms += st.kernel_ms; agg.rays += st.rays; agg.shadow_rays += st.shadow_rays; agg.sphere_tests += st.sphere_tests; }
+    }
+  }
+  if (stats) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint64_t px = 0;
+    for (uint32_t i = 0; i < tiles->n_tiles; i++) {
+      const uint64_t r0 = (uint64_t)(tiles->tile_first + (uint64_t)i * tiles->tile_stride) * tiles->tile_rows;
+      if (r0 < h) px += ((r0 + tiles->tile_rows <= h) ? tiles->tile_rows : (h - r0)) * (uint64_t)w;
+    }
+    agg.pixels = px * n_frames;
+    agg.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    *stats = agg;
+  }
+  return RT_OK;
+}
+
 int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
-                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats) {
+                      void *const *d_frames, void *hip_stream, uint32_t flags, rt_stats *stats, uint32_t ss_override) {
   if (!s || !tiles) return fail(RT_ERR_INVALID, "NULL scene, tiles or output");
   if (n_frames == 0 || n_frames > 65535u) return fail(RT_ERR_INVALID, "n_frames %u not in 1..65535", n_frames);
   if ((frame_stride_bytes & 3u) != 0) return fail(RT_ERR_INVALID, "frame stride must be a multiple of 4 bytes");
@@ -629,7 +857,9 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   const auto t_begin = std::chrono::steady_clock::now();
 
   const rt_scene_header &hd = s->hd;
-  const bool ss2 = hd.supersample == 2;
+  const uint32_t ss = ss_override ? ss_override : hd.supersample;
+  if (ss > 2u) return render_supersampled(s, ss, w, h, tiles, n_frames, d_out, frame_stride_bytes, d_frames, stream, flags, stats);
+  const bool ss2 = ss == 2u;
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   // Which kernel.  The product (FMA) kernel unless the caller asks for the strict one - or the scene itself sits on an exact
   // coincidence whose outcome in the reference is decided by the last bit of its own arithmetic (s->needs_strict, see
@@ -694,6 +924,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   L.scatter = d_frames ? 1u : 0u;
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
+  L.ray_bias[0] = 0.5 - L.proj_w; L.ray_bias[1] = L.proj_h - 0.5; L.ray_bias[2] = L.cam_axis_sum[2] * L.proj_d;
   L.win_w = L.win_h = ~0u;                                       // the whole frame
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
 #ifdef RT_TESTING
@@ -707,6 +938,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   } ev;
   hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+  static const bool no_order = RT_TEST_ENV("RT_NO_DISPATCH_ORDER") != nullptr;    // A/B switch (test build): the grid's own order
+  if (!strict_main) {
+    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order);
+    if (!L.order) return RT_ERR_DEVICE;
+  }
   int err = (strict_main ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, lds_for(strict_main), stream);
   // Centre row / centre column of a sample grid with an ODD number of rows / columns.  The primary rays there have a direction
   // component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they spawn that stays in that
@@ -720,6 +956,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     const uint32_t ssf = ss2 ? 2u : 1u;
     const bool odd_rows = ((h * ssf) & 1u) != 0, odd_cols = ((w * ssf) & 1u) != 0;
     rt_launch F = L;
+    F.order = nullptr;
     bind_kernel(F, true);
     F.counters = D.d_counters;
     if (odd_rows) {
@@ -986,13 +1223,27 @@ int scene_for(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
   return RT_OK;
 }
 
-int ensure_frame(device_state &D, size_t bytes) {
+// A device allocation must live on the device it was made for: every hipMalloc of the multi-GPU path is checked against
+// hipPointerGetAttributes (a wrong current device would otherwise only show as a fault, or as silent xGMI traffic, on a real
+// multi-GPU node - nothing a one-GPU box can catch).
+int check_on_device(const void *p, const device_state &D, const char *what) {
+  hipPointerAttribute_t attr;
+  HIP_TRY(hipPointerGetAttributes(&attr, p));
+  if (attr.device != D.hip_id) return fail(RT_ERR_DEVICE, "%s was allocated on HIP device %d, expected %d", what, attr.device, D.hip_id);
+  return RT_OK;
+}
+
+// rt_render's per-device scratch frame, allocated with THAT device current (ensure_device does the hipSetDevice)
+int ensure_frame(int device, size_t bytes) {
+  int rc = ensure_device(device);
+  if (rc) return rc;
+  device_state &D = G.dev[device];
   if (D.frame_bytes >= bytes) return RT_OK;
   if (D.d_frame) (void)hipFree(D.d_frame);
   D.d_frame = nullptr; D.frame_bytes = 0;
   HIP_TRY(hipMalloc(&D.d_frame, bytes));
   D.frame_bytes = bytes;
-  return RT_OK;
+  return check_on_device(D.d_frame, D, "rt_render's frame buffer");
 }
 }  // namespace
 
@@ -1000,7 +1251,12 @@ int ensure_frame(device_state &D, size_t bytes) {
 namespace {
 int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats,
                    uint32_t want_bands, rt_band_callback on_band, void *user);
+int g_last_plan = 0;      // how the last rt_render put its frame together: 0 one GPU, 1 peer stores, 2 ncclGather (or its emulation)
 }  // namespace
+
+#ifdef RT_TESTING
+extern "C" int rt_test_last_plan(void) { return g_last_plan; }
+#endif
 
 extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats) {
   return render_to_host(blob, bytes, w, h, out_rgba, flags, stats, 0u, nullptr, nullptr);
@@ -1027,13 +1283,17 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
   rt_stats agg;
   memset(&agg, 0, sizeof agg);
 
-  if (ndev == 1 || h < (uint32_t)ndev * RT_TILE_H) {
+  // test build: RT_FORCE_GATHER=1 takes the ncclGather plan - also with ONE device, which runs the real RCCL symbols
+  // (ncclCommInitAll, ncclGroupStart/End, ncclGather with one rank) on a one-GPU box
+  const bool force_gather = RT_TEST_ENV("RT_FORCE_GATHER") != nullptr;
+  g_last_plan = 0;
+  if ((ndev == 1 && !force_gather) || h < (uint32_t)ndev * RT_TILE_H) {
     // ---- one GPU.  Large frames are rendered as a few row bands so that the PCIe copy-out of band i (copy
     //      stream) runs while band i+1 renders (render stream): the frame costs ~max(render, copy), not the sum ----
     rt_scene_dev *s = nullptr;
     if ((rc = scene_for(0, blob, bytes, &s))) return rc;
     device_state &D = G.dev[0];
-    rc = ensure_frame(D, frame_bytes);
+    rc = ensure_frame(0, frame_bytes);                             // (makes device 0 current: a previous multi-GPU call may have left another one)
     if (!rc && !D.copy_stream) {
       hipError_t e = hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking);
       if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy stream: %s", hipGetErrorString(e));
@@ -1084,8 +1344,12 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
           const uint32_t r0 = b * band_rows;
           if (e == hipSuccess) on_band(user, r0, (r0 + band_rows <= h) ? band_rows : h - r0);
         }
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.stream);
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(D.copy_stream);
+        // on EVERY way out the copies already queued into the caller's buffer are finished first: the caller may hand that
+        // (pinned) buffer back to the pool as soon as this returns
+        {
+          const hipError_t e1 = hipStreamSynchronize(D.stream), e2 = hipStreamSynchronize(D.copy_stream);
+          if (e == hipSuccess) e = (e1 != hipSuccess) ? e1 : e2;
+        }
         if (e == hipSuccess && !rc) { float ms = 0.f; e = hipEventElapsedTime(&ms, ev0, ev1); st.kernel_ms = ms; }
         if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "banded render/copy-out: %s", hipGetErrorString(e));
         st.pixels = (uint64_t)w * h;
@@ -1098,66 +1362,122 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
     }
     if (rc) return rc;
   } else {
-    // ---- G GPUs of one node: interleaved row tiles (sky rows are cheap, floor rows are not), each
-    //      GPU stores its tiles contiguously, ONE RCCL gather to GPU 0 over xGMI, one de-interleave pass ----
-    if (!G.emulated && (rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
+    // ---- G GPUs of one node (one process): interleaved row tiles (sky rows are cheap, floor rows are not), reassembled
+    //      on GPU 0.  Primary plan: PEER STORES - every GPU's kernel writes its tiles straight into GPU 0's frame buffer over
+    //      xGMI (hipDeviceEnablePeerAccess; rows at their place in the frame, whole 128-byte lines: the scatter store), so
+    //      there is no gather buffer, no collective and no de-interleave pass.  Fallback (no peer access between some pair,
+    //      or the test build's RT_FORCE_GATHER): RGB24 bands, ONE ncclGather to GPU 0, one de-interleave pass. ----
     const uint32_t tile_rows = (h >= (uint32_t)ndev * 64u) ? 16u : RT_TILE_H;
     const uint32_t n_tiles_total = (h + tile_rows - 1) / tile_rows;
     const uint32_t tiles_per_rank = (n_tiles_total + ndev - 1) / ndev;
-    // bands cross xGMI as RGB24 when the width allows it (the alpha byte is the constant 255, main.js:198; the
-    // de-interleave restores it); tile_rows >= 8, so a band is a multiple of 96 bytes and d_final stays 16-byte aligned
-    const bool rgb24 = (w & 3u) == 0;
-    const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * (rgb24 ? 3u : 4u);
+    bool peer_plan = !force_gather;
+    for (int g = 1; g < ndev && peer_plan && !G.emulated; g++) {
+      device_state &D = G.dev[g];
+      if (D.peer_to_root == 0) {
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, D.hip_id, G.dev[0].hip_id);
+        if (e == hipSuccess && can) {
+          e = hipSetDevice(D.hip_id);
+          if (e == hipSuccess) e = hipDeviceEnablePeerAccess(G.dev[0].hip_id, 0);
+          if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        }
+        D.peer_to_root = (e == hipSuccess && can) ? 1 : -1;
+      }
+      if (D.peer_to_root < 0) peer_plan = false;
+    }
     std::vector<rt_scene_dev *> scenes(ndev, nullptr);
-    rc = RT_OK;
-    for (int g = 0; g < ndev && !rc; g++) {
-      rc = scene_for(g, blob, bytes, &scenes[g]);
-      if (!rc) rc = ensure_frame(G.dev[g], band_bytes);
-    }
-    if (!rc) {                                   // (the scenes stay cached on their devices)
-      device_state &R = G.dev[0];
-      hipError_t e = hipSetDevice(R.hip_id);
-      if (e == hipSuccess && R.gather_bytes < band_bytes * ndev + frame_bytes) {
-        if (R.d_gather) (void)hipFree(R.d_gather);
-        R.d_gather = nullptr; R.gather_bytes = 0;
-        e = hipMalloc(&R.d_gather, band_bytes * ndev + frame_bytes);
-        if (e == hipSuccess) R.gather_bytes = band_bytes * ndev + frame_bytes;
-      }
-      if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "gather buffer: %s", hipGetErrorString(e));
-    }
     std::vector<hipEvent_t> ev0(ndev, nullptr), ev1(ndev, nullptr);
-    for (int g = 0; g < ndev && !rc; g++) {
-      rt_tiles t = {tile_rows, (uint32_t)g, (uint32_t)ndev, tiles_per_rank};
-      if ((rc = ensure_device(g))) break;
-      (void)hipEventCreate(&ev0[g]); (void)hipEventCreate(&ev1[g]);
-      (void)hipEventRecord(ev0[g], G.dev[g].stream);
-      rc = rt_render_tiles_device(scenes[g], w, h, &t, G.dev[g].d_frame, nullptr, (flags & ~RT_FLAG_COUNT) | (rgb24 ? RT_FLAG_RGB24 : 0u), nullptr);
-      (void)hipEventRecord(ev1[g], G.dev[g].stream);
-    }
-    if (!rc && G.emulated) {                      // one physical GPU: the gather is a set of device-to-device copies
+    const uint32_t kflags = flags & ~(uint32_t)RT_FLAG_COUNT;
+    rc = RT_OK;
+    if (peer_plan) {
+      for (int g = 0; g < ndev && !rc; g++) rc = scene_for(g, blob, bytes, &scenes[g]);     // (the scenes stay cached on their devices)
+      if (!rc) rc = ensure_frame(0, frame_bytes);
+      void *root_frame[1] = {G.dev[0].d_frame};
+      for (int g = 0; g < ndev && !rc; g++) {
+        rt_tiles t = {tile_rows, (uint32_t)g, (uint32_t)ndev, tiles_per_rank};
+        if ((rc = ensure_device(g))) break;
+        hipError_t e = hipEventCreate(&ev0[g]);
+        if (e == hipSuccess) e = hipEventCreate(&ev1[g]);
+        if (e == hipSuccess) e = hipEventRecord(ev0[g], G.dev[g].stream);
+        if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e)); break; }
+        rc = rt_render_scatter_device(scenes[g], w, h, &t, 1u, root_frame, nullptr, kflags, nullptr);
+        if (!rc && (e = hipEventRecord(ev1[g], G.dev[g].stream)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e));
+      }
+      // every GPU's stores have landed in GPU 0's frame once its stream is drained; then the copy-out
       for (int g = 0; g < ndev; g++) {
-        hipError_t e = hipMemcpyAsync((uint8_t *)G.dev[0].d_gather + band_bytes * g, G.dev[g].d_frame, band_bytes, hipMemcpyDeviceToDevice, G.dev[g].stream);
+        if (!G.dev[g].stream) continue;
+        hipError_t e = hipSetDevice(G.dev[g].hip_id);
         if (e == hipSuccess) e = hipStreamSynchronize(G.dev[g].stream);
-        if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "emulated gather: %s", hipGetErrorString(e));
+        if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "peer-store plan, device %d: %s", g, hipGetErrorString(e));
       }
-    } else if (!rc) {
-      NCCL.group_start();
-      for (int g = 0; g < ndev; g++) {
-        (void)hipSetDevice(G.dev[g].hip_id);
-        const int r = NCCL.gather(G.dev[g].d_frame, g == 0 ? G.dev[0].d_gather : nullptr, band_bytes, NCCL_UINT8, 0, G.comms[g], G.dev[g].stream);
-        if (r != 0 && !rc) rc = fail(RT_ERR_DEVICE, "ncclGather: %s", NCCL.errstr(r));
-      }
-      NCCL.group_end();
-    }
-    if (!rc) {
-      device_state &R = G.dev[0];
-      uint8_t *d_final = (uint8_t *)R.d_gather + band_bytes * ndev;
-      rc = (rgb24 ? rt_deinterleave_rgb24_device : rt_deinterleave_device)(0, R.d_gather, d_final, w, h, tile_rows, (uint32_t)ndev, band_bytes, nullptr);
       if (!rc) {
-        (void)hipSetDevice(R.hip_id);
-        hipError_t e = hipMemcpyAsync(out_rgba, d_final, frame_bytes, hipMemcpyDeviceToHost, R.stream);
+        device_state &R = G.dev[0];
+        hipError_t e = hipSetDevice(R.hip_id);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_rgba, R.d_frame, frame_bytes, hipMemcpyDeviceToHost, R.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
         if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+      }
+    } else {
+      if (!G.emulated && (rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
+      // bands cross xGMI as RGB24 when the width allows it (the alpha byte is the constant 255, main.js:198; the
+      // de-interleave restores it); tile_rows >= 8, so a band is a multiple of 96 bytes and d_final stays 16-byte aligned
+      const bool rgb24 = (w & 3u) == 0;
+      const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * (rgb24 ? 3u : 4u);
+      for (int g = 0; g < ndev && !rc; g++) {
+        rc = scene_for(g, blob, bytes, &scenes[g]);
+        if (!rc) rc = ensure_frame(g, band_bytes);
+      }
+      if (!rc && !(rc = ensure_device(0))) {
+        device_state &R = G.dev[0];
+        if (R.gather_bytes < band_bytes * ndev + frame_bytes) {
+          if (R.d_gather) (void)hipFree(R.d_gather);
+          R.d_gather = nullptr; R.gather_bytes = 0;
+          hipError_t e = hipMalloc(&R.d_gather, band_bytes * ndev + frame_bytes);
+          if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "gather buffer: %s", hipGetErrorString(e));
+          else { R.gather_bytes = band_bytes * ndev + frame_bytes; rc = check_on_device(R.d_gather, R, "rt_render's gather buffer"); }
+        }
+      }
+      for (int g = 0; g < ndev && !rc; g++) {
+        rt_tiles t = {tile_rows, (uint32_t)g, (uint32_t)ndev, tiles_per_rank};
+        if ((rc = ensure_device(g))) break;
+        hipError_t e = hipEventCreate(&ev0[g]);
+        if (e == hipSuccess) e = hipEventCreate(&ev1[g]);
+        if (e == hipSuccess) e = hipEventRecord(ev0[g], G.dev[g].stream);
+        if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e)); break; }
+        rc = rt_render_tiles_device(scenes[g], w, h, &t, G.dev[g].d_frame, nullptr, kflags | (rgb24 ? RT_FLAG_RGB24 : 0u), nullptr);
+        if (!rc && (e = hipEventRecord(ev1[g], G.dev[g].stream)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e));
+      }
+      if (!rc && G.emulated) {                      // one physical GPU: the gather is a set of device-to-device copies
+        for (int g = 0; g < ndev; g++) {
+          hipError_t e = hipMemcpyAsync((uint8_t *)G.dev[0].d_gather + band_bytes * g, G.dev[g].d_frame, band_bytes, hipMemcpyDeviceToDevice, G.dev[g].stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(G.dev[g].stream);
+          if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "emulated gather: %s", hipGetErrorString(e));
+        }
+      } else if (!rc) {
+        // one ncclGather per device inside one group; a group that was opened is always closed, and every return code counts
+        int r = NCCL.group_start();
+        if (r != 0) rc = fail(RT_ERR_DEVICE, "ncclGroupStart: %s", NCCL.errstr(r));
+        else {
+          for (int g = 0; g < ndev && !rc; g++) {
+            hipError_t e = hipSetDevice(G.dev[g].hip_id);
+            if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "hipSetDevice(%d): %s", G.dev[g].hip_id, hipGetErrorString(e)); break; }
+            r = NCCL.gather(G.dev[g].d_frame, g == 0 ? G.dev[0].d_gather : nullptr, band_bytes, NCCL_UINT8, 0, G.comms[g], G.dev[g].stream);
+            if (r != 0) rc = fail(RT_ERR_DEVICE, "ncclGather on device %d: %s", g, NCCL.errstr(r));
+          }
+          r = NCCL.group_end();
+          if (r != 0 && !rc) rc = fail(RT_ERR_DEVICE, "ncclGroupEnd: %s", NCCL.errstr(r));
+        }
+      }
+      if (!rc) {
+        device_state &R = G.dev[0];
+        uint8_t *d_final = (uint8_t *)R.d_gather + band_bytes * ndev;
+        rc = (rgb24 ? rt_deinterleave_rgb24_device : rt_deinterleave_device)(0, R.d_gather, d_final, w, h, tile_rows, (uint32_t)ndev, band_bytes, nullptr);
+        if (!rc) {
+          hipError_t e = hipSetDevice(R.hip_id);
+          if (e == hipSuccess) e = hipMemcpyAsync(out_rgba, d_final, frame_bytes, hipMemcpyDeviceToHost, R.stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
+          if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy-out: %s", hipGetErrorString(e));
+        }
       }
     }
     for (int g = 0; g < ndev; g++) {
@@ -1170,8 +1490,10 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
       if (ev0[g]) (void)hipEventDestroy(ev0[g]);
       if (ev1[g]) (void)hipEventDestroy(ev1[g]);
     }
+    (void)hipSetDevice(G.dev[0].hip_id);
     if (rc) return rc;
     agg.pixels = (uint64_t)w * h;
+    g_last_plan = peer_plan ? 1 : 2;
     if (on_band) on_band(user, 0u, h);           // several GPUs: the frame arrives whole
   }
   agg.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -48,6 +48,7 @@ struct rt_launch {
   // camera + projection (main.js:85-105), projection constants computed on the host in binary64
   double cam_origin[3], cam_axis_x[3], cam_axis_y[3], cam_axis_z[3];
   double cam_axis_sum[3];            // axisX[k] + axisY[k] + axisZ[k] (product kernel's ray generation)
+  double ray_bias[3];                // product kernel: {0.5 - proj_w, proj_h - 0.5, axis_sum.z * proj_d}
   double proj_w, proj_h, proj_d;     // of the SAMPLE grid (2w x 2h when supersampling)
   double epsilon, light_intensity, miss_color[3];
   double lights[RT_MAX_LIGHTS][3];
@@ -65,6 +66,10 @@ struct rt_launch {
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
   uint32_t *out_frames[RT_MAX_SCATTER];
+  // Launch table of the product kernel (rt_api.hip: dispatch_order): workgroup b of the flat grid renders the tile described by
+  // entry b = {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band}; the host lists the tiles
+  // dearest first, so that a launch ends on cheap tiles.  The strict kernel runs on the plain 2-D grid and ignores it.
+  const uint32_t *order;
   // Fix-up launches (strict kernel only, rt_api.hip render_batch_impl): the grid starts at workgroup (bx0, by0) and only the
   // pixels of the window [win_x0, win_x0 + win_w) x [win_y0, win_y0 + win_h) (frame coordinates) are stored.
   uint32_t bx0, by0, win_x0, win_w, win_y0, win_h;

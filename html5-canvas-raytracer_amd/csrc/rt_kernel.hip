@@ -185,9 +185,18 @@ __device__ __forceinline__ int to_int32_bit0(double x) {
 
 // Uint8ClampedArray store of 255*c (main.js:195-197): NaN -> 0, clamp, round half to even
 __device__ __forceinline__ uint32_t to_byte(double c) {
+#if RT_STRICT
   // fmax(NaN, 0) = 0 and the clamp precede the conversion, so v_cvt_u32_f64 never sees an out-of-range
   // value; v_rndne_f64 rounds half to even.
   return (uint32_t)__builtin_rint(__builtin_fmin(__builtin_fmax(255.0 * c, 0.0), 255.0));
+#else
+  // Three operations instead of five: clamp c itself to [0,1] (fmax(NaN, 0) = 0), then ONE fma adds 255*c to 1.5*2^52, whose
+  // ulp is 1: the sum's low mantissa word IS the byte, rounded half to even by the fma's own rounding - of the exact product,
+  // where the reference rounds fl(255*c); the two differ only when fl(255*c) lands exactly on k + 1/2 and 255*c does not
+  // (~2^-45 of the values), and then by the 1 LSB the product kernel is allowed.
+  const double s = __builtin_fma(__builtin_fmin(__builtin_fmax(c, 0.0), 1.0), 255.0, 6755399441055744.0);
+  return (uint32_t)__builtin_bit_cast(unsigned long long, s);
+#endif
 }
 
 // main.js:420-439, as a "candidate root" test.  With thc >= 0 (or NaN) the reference's two-armed
@@ -215,18 +224,15 @@ typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 // Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
 // again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
 // the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
-struct rt_pixel { uint32_t px, trow, frow, lrow, sub; bool valid; };
+struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid; bool valid; };
+#if RT_STRICT
 template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
   // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
   // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
-#if RT_STRICT
   const uint32_t tile_x = blockIdx.x + L.bx0, by = blockIdx.y + L.by0;   // fix-up launches cover part of the grid (rt_device.h)
-#else
-  const uint32_t tile_x = blockIdx.x, by = blockIdx.y;
-#endif
   uint32_t tile_i, row_block;
   if (L.n_tiles == 1u) { tile_i = 0u; row_block = by; }
   else if (L.rb_shift != ~0u) { tile_i = by >> L.rb_shift; row_block = by & ((1u << L.rb_shift) - 1u); }
@@ -238,11 +244,34 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
   P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
   P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
-#if RT_STRICT
   P.valid = P.valid && (P.px - L.win_x0 < L.win_w) && (P.frow - L.win_y0 < L.win_h);
-#endif
+  P.rows_valid = 0u;                                   // (product kernel only)
   return P;
 }
+#else
+// Product kernel: a FLAT grid (workgroups, 1, frames of the batch) and a host-built table with one 8-byte entry per workgroup:
+//   word 0 = tile_x | rows_valid << 11 | first frame row << 15      word 1 = first row in this call's output band
+// (rt_api.hip: dispatch_order).  One scalar load replaces the tile / row-block arithmetic of the plain grid - no division, no
+// tile parameters in registers - and lets the host choose the ORDER in which the hardware hands the tiles out: dearest first,
+// so that a launch ends on cheap sky tiles instead of on the floor.  trow is the row inside the workgroup's block here.
+template <bool SS2>
+__device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  typedef const unsigned long long __attribute__((address_space(4))) *order_kptr;
+  const unsigned long long e64 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)blockIdx.x << 3));   // s_load_dwordx2
+  const uint32_t e0 = (uint32_t)e64, e1 = (uint32_t)(e64 >> 32);
+  const uint32_t tile_x = e0 & 2047u, rows_valid = (e0 >> 11) & 15u, frow0 = e0 >> 15;
+  rt_pixel P;
+  P.sub = 0u;
+  if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = lane >> 3; }
+  else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = q >> 3; }
+  P.frow = frow0 + P.trow;
+  P.lrow = e1 + P.trow;
+  P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
+  P.valid = (P.px < L.w) && (P.trow < rows_valid);
+  return P;
+}
+#endif
 
 // A frame of the explicit recursion stack: everything intersectWorld still needs after its
 // recursive calls return (main.js:320-336) — the lighting and sampler terms do not depend on the
@@ -924,7 +953,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
 
   // ---- A1 primary ray (main.js:186-193); dist is indexed by component k, not by axis (q1) ----
+#if RT_STRICT
   const double d0 = ((double)sx - L.proj_w) + 0.5, d1 = (L.proj_h - (double)sy) - 0.5, d2 = L.proj_d;
+#else
+  // the same numbers with one addition each: sx, sy are integers and proj_w, proj_h half-integers far below 2^52, so
+  // sx + (0.5 - proj_w) and (proj_h - 0.5) - sy are exact, like the reference's two-step forms
+  const double d0 = (double)sx + L.ray_bias[0], d1 = L.ray_bias[1] - (double)sy;
+#endif
   const v3 o = mk(L.cam_origin[0], L.cam_origin[1], L.cam_origin[2]);
   double rl;
 #if RT_STRICT
@@ -936,7 +971,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   // target[k] - origin[k] = (axisX[k] + axisY[k] + axisZ[k]) * dist[k]; the sums come from the host
   // (its z component is axis_sum.z * projD: never the zero vector unless the camera is degenerate, and then the
   // reference divides by zero as well, so no zero-length select here)
-  const v3 rawray = mk(L.cam_axis_sum[0] * d0, L.cam_axis_sum[1] * d1, L.cam_axis_sum[2] * d2);
+  const v3 rawray = mk(L.cam_axis_sum[0] * d0, L.cam_axis_sum[1] * d1, L.ray_bias[2]);      // [2] = axis_sum.z * projD, from the host
   rl = rt_rsqrt_pos(dot(rawray, rawray));
   const v3 ray = mk(rawray.x * rl, rawray.y * rl, rawray.z * rl);
 #endif
@@ -997,11 +1032,11 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     const uint32_t dr = rr - (lane2 >> 3);              // row of the tile: difference in wrap-around arithmetic
     const uint32_t trow2 = P1.trow + dr, frow2 = P1.frow + dr;
 #if RT_STRICT
-    const bool in_win = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h);
+    const bool row_ok2 = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h) && trow2 < L.tile_rows && frow2 < L.h;
 #else
-    const bool in_win = true;
+    const bool row_ok2 = trow2 < P1.rows_valid;        // rows of the block inside its tile and the frame (from the table entry)
 #endif
-    if (in_win && px2 < L.w && trow2 < L.tile_rows && frow2 < L.h) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
+    if (row_ok2 && px2 < L.w) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
   } else if (!L.rgb24) {                               // wave-uniform
     if (valid && P1.sub == 0u) out[(size_t)orow * L.w + P1.px] = rgbw | 0xff000000u;
   } else {
@@ -1021,7 +1056,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     // a window's columns are whole 8-pixel groups (rt_api.hip), so the group's first pixel decides
     const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h) && (x0 - L.win_x0 < L.win_w) && (P1.frow - L.win_y0 < L.win_h);
 #else
-    const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h);
+    const bool row_ok = P1.trow < P1.rows_valid;
 #endif
     if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
   }
@@ -1043,7 +1078,8 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
   // x: 32-pixel tiles across the frame; y: tiles x row blocks (8 rows, or 2 when supersampling); z: frames
   (void)ss2;
   // (a fix-up launch of the strict kernel covers part of that grid: L->grid_x / grid_y, when set)
-  const dim3 grid(L->grid_x ? L->grid_x : L->tiles_x, L->grid_y ? L->grid_y : L->n_tiles * L->rb_per_tile, L->n_frames), block(RT_WG_THREADS);
+  const dim3 grid(L->grid_x ? L->grid_x : (L->order ? L->tiles_x * L->n_tiles * L->rb_per_tile : L->tiles_x),
+                  L->grid_y ? L->grid_y : (L->order ? 1u : L->n_tiles * L->rb_per_tile), L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
   // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
   const bool grid_variant = !RT_STRICT && !count && (L->shadow_grid != nullptr || L->bounce_table != nullptr);

@@ -58,6 +58,10 @@ function renderProgressive(width, height, sceneObj, opts) {
   return r.promise.then((stats) => { r.data.stats = stats; return r.data; });
 }
 
+// `const build = '741'` (main.js:3) + this library's revision; every render's `.stats` also carries `.build` and `.report`, the
+// reference's end-of-frame string 'build #<id> (<elapsed>ms)' (main.js:204-205) for that render.
+function buildId() { return native().buildId(); }
+
 function shutdown() { if (addon) addon.shutdown(); inited = false; }
 
-module.exports = Object.assign({render, renderAsync, renderProgressive, init, shutdown, flattenScene, scenes, native}, scene);
+module.exports = Object.assign({render, renderAsync, renderProgressive, init, shutdown, buildId, flattenScene, scenes, native}, scene);

@@ -122,7 +122,7 @@ function createScene(opts) {
     light_intensity: opts.light_intensity === undefined ? 50 : opts.light_intensity, // main.js:284
     textures: opts.textures || [],
     epsilon: opts.epsilon === undefined ? 0.001 : opts.epsilon,                 // main.js:430-436
-    supersample: opts.supersample || 1,                                         // 1, or 2 = 2x2 box (cfg5)
+    supersample: opts.supersample || 1,                                         // 1, or k = 2 (cfg5), 3, 4: k x k box of the kw x kh frame
   };
   validateScene(scene);
   return scene;
@@ -136,7 +136,7 @@ function validateScene(scene) {
   const c = scene.camera;
   if (!c || !isVec(c.origin, 3) || !isVec(c.axisX, 3) || !isVec(c.axisY, 3) || !isVec(c.axisZ, 3)) throw new Error('scene.camera must hold origin/axisX/axisY/axisZ 3-vectors');
   if (!Number.isInteger(scene.segs) || scene.segs < 0 || scene.segs > 16) throw new Error('scene.segs must be an integer in [0,16]');
-  if (!(scene.supersample === 1 || scene.supersample === 2)) throw new Error('scene.supersample must be 1 or 2');
+  if (![1, 2, 3, 4].includes(scene.supersample)) throw new Error('scene.supersample must be 1, 2, 3 or 4');
   if (!Array.isArray(scene.objects) || scene.objects.length < 1 || scene.objects.length > 256) throw new Error('scene.objects must hold 1..256 spheres');
   if (!Array.isArray(scene.lights) || scene.lights.length > 16) throw new Error('scene.lights must hold 0..16 lights');
   scene.lights.forEach((l) => { if (!isVec(l, 3)) throw new Error('light must be a 3-vector'); });

@@ -7,7 +7,7 @@
 //
 //   GET /                               the page
 //   GET /frame?scene=h8&w=1280&h=720    raw RGBA8, w*h*4 bytes (ImageData.data layout);
-//                                       headers X-Width, X-Height, X-Kernel-Ms, X-Total-Ms
+//                                       headers X-Width, X-Height, X-Kernel-Ms, X-Total-Ms, X-Build, X-Report ('build #741.r2 (12ms)')
 //   GET /frame?...&progressive=8        the same bytes as a CHUNKED response, one chunk per row band as it leaves the
 //                                       GPU (renderProgressive): the page paints top to bottom like the reference's
 //                                       scanline loop (main.js:183-201)
@@ -49,8 +49,11 @@ const PAGE = `<!DOCTYPE html>
     const rows = Math.floor(got / (w * 4));
     if (rows > painted) { ctx.putImageData(new ImageData(data.subarray(painted * w * 4, rows * w * 4), w, rows - painted), 0, painted); painted = rows; }
   }
-  ctx.font = '16px monospace'; ctx.textBaseline = 'top'; ctx.fillStyle = '#ffffff';
-  ctx.fillText('MI355X, round trip ' + (Date.now() - t0) + 'ms', 0, 0);
+  // the reference's end-of-frame overlay (main.js:203-210), same string, font and placement: 'build #<id> (<elapsed>ms)' with
+  // elapsed measured here, in the browser, around the whole frame as the reference measures it
+  const message = 'build #' + (r.headers.get('X-Build') || '?') + ' (' + (Date.now() - t0) + 'ms)';
+  ctx.font = '16px monospace'; ctx.textAlign = 'left'; ctx.textBaseline = 'top'; ctx.fillStyle = '#ffffff';
+  ctx.fillText(message, 0, 0);
 })();
 </script></body></html>`;
 
@@ -98,20 +101,21 @@ function createServer(opts) {
         let started = false;
         return RT.renderProgressive(w, h, scene, {bands: Math.min(bands, 64), onBand: (b) => {
           if (!started) {
-            res.writeHead(200, {'Content-Type': 'application/octet-stream', 'X-Width': w, 'X-Height': h, 'Cache-Control': 'no-store',
-              'Trailer': 'X-Kernel-Ms, X-Total-Ms'});
+            res.writeHead(200, {'Content-Type': 'application/octet-stream', 'X-Width': w, 'X-Height': h, 'X-Build': RT.buildId(), 'Cache-Control': 'no-store',
+              'Trailer': 'X-Kernel-Ms, X-Total-Ms, X-Report'});
             started = true;
           }
           res.write(Buffer.from(b.data.buffer, b.data.byteOffset, b.data.length));
         }}).then((data) => {
-          res.addTrailers({'X-Kernel-Ms': data.stats.kernel_ms.toFixed(3), 'X-Total-Ms': data.stats.total_ms.toFixed(3)});
+          res.addTrailers({'X-Kernel-Ms': data.stats.kernel_ms.toFixed(3), 'X-Total-Ms': data.stats.total_ms.toFixed(3), 'X-Report': data.stats.report});
           res.end();
         }).catch((e) => { if (started) res.destroy(e); else sendJSON(res, 503, {error: e.message}); });
       }
       // renderAsync keeps the event loop free while the GPU works; the reply streams the pinned frame
       return RT.renderAsync(w, h, scene).then((data) => {
         res.writeHead(200, {'Content-Type': 'application/octet-stream', 'Content-Length': data.length, 'X-Width': w, 'X-Height': h,
-          'X-Kernel-Ms': data.stats.kernel_ms.toFixed(3), 'X-Total-Ms': data.stats.total_ms.toFixed(3), 'Cache-Control': 'no-store'});
+          'X-Kernel-Ms': data.stats.kernel_ms.toFixed(3), 'X-Total-Ms': data.stats.total_ms.toFixed(3), 'X-Build': data.stats.build, 'X-Report': data.stats.report,
+          'Cache-Control': 'no-store'});
         res.end(Buffer.from(data.buffer, data.byteOffset, data.length));
       }).catch((e) => sendJSON(res, 503, {error: e.message}));
     }

@@ -104,6 +104,8 @@ napi_value make_result(napi_env env, args *a) {
   napi_create_double(env, (double)a->st.rays, &v); napi_set_named_property(env, stats, "rays", v);
   napi_create_double(env, (double)a->st.shadow_rays, &v); napi_set_named_property(env, stats, "shadow_rays", v);
   napi_create_double(env, (double)a->st.sphere_tests, &v); napi_set_named_property(env, stats, "sphere_tests", v);
+  { char rep[96]; napi_value sv; if (rt_elapsed_report(&a->st, rep, sizeof rep) > 0) { napi_create_string_utf8(env, rep, NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "report", sv); }
+    napi_create_string_utf8(env, rt_build_id(), NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "build", sv); }
   napi_set_named_property(env, res, "stats", stats);
   return res;
 }
@@ -220,6 +222,8 @@ void prog_finalize(napi_env env, void *data, void *) {
     napi_create_double(env, a->st.kernel_ms, &v); napi_set_named_property(env, stats, "kernel_ms", v);
     napi_create_double(env, a->st.total_ms, &v); napi_set_named_property(env, stats, "total_ms", v);
     napi_create_double(env, (double)a->st.pixels, &v); napi_set_named_property(env, stats, "pixels", v);
+    { char rep[96]; napi_value sv; if (rt_elapsed_report(&a->st, rep, sizeof rep) > 0) { napi_create_string_utf8(env, rep, NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "report", sv); }
+      napi_create_string_utf8(env, rt_build_id(), NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "build", sv); }
     napi_resolve_deferred(env, a->deferred, stats);
   } else {
     napi_value msg, err;
@@ -266,6 +270,13 @@ napi_value RenderProgressive(napi_env env, napi_callback_info info) {
 
 napi_value Shutdown(napi_env, napi_callback_info) { rt_shutdown(); return nullptr; }
 
+// main.js:3 / :204-205: the build stamp and the end-of-frame report 'build #<id> (<elapsed>ms)'
+napi_value BuildId(napi_env env, napi_callback_info) {
+  napi_value v;
+  napi_create_string_utf8(env, rt_build_id(), NAPI_AUTO_LENGTH, &v);
+  return v;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) {
   napi_value v;
   napi_create_uint32(env, rt_abi_version(), &v);
@@ -296,6 +307,7 @@ napi_value Module(napi_env env, napi_value exports) {
       {"validate", nullptr, Validate, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"shutdown", nullptr, Shutdown, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"buildId", nullptr, BuildId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

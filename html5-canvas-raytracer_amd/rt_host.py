@@ -61,8 +61,8 @@ def validate_scene(scene):
             raise ValueError("scene.camera.%s must be a 3-vector" % k)
     if not (isinstance(scene["segs"], int) and 0 <= scene["segs"] <= 16):
         raise ValueError("scene.segs must be an integer in [0,16]")
-    if scene.get("supersample", 1) not in (1, 2):
-        raise ValueError("scene.supersample must be 1 or 2")
+    if scene.get("supersample", 1) not in (1, 2, 3, 4):
+        raise ValueError("scene.supersample must be 1, 2, 3 or 4")
     if not (1 <= len(scene["objects"]) <= 256):
         raise ValueError("scene.objects must hold 1..256 spheres")
     if len(scene["lights"]) > 16:
@@ -143,6 +143,8 @@ ABI = {
     "rt_device_count": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
+    "rt_build_id": (C.c_char_p, []),
+    "rt_elapsed_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "rt_scene_validate": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_scene_cull_rects": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
     "rt_scene_bounce_candidates": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -257,6 +259,21 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def build_id(lib=None):
+    """`const build = '741'` (main.js:3) + the library's revision, e.g. '741.r2'."""
+    return (lib or load_library()).rt_build_id().decode()
+
+
+def elapsed_report(stats, lib=None):
+    """The reference's end-of-frame string for a finished render (main.js:204-205): 'build #<id> (<elapsed>ms)'."""
+    lib = lib or load_library()
+    buf = C.create_string_buffer(96)
+    n = lib.rt_elapsed_report(C.byref(stats), buf, len(buf))
+    if n < 0:
+        raise RtError("rt_elapsed_report failed: " + lib.rt_last_error().decode())
+    return buf.value.decode()
 
 
 def render(width, height, scene, flags=0, lib=None, max_devices=1):

@@ -33,6 +33,10 @@ extern "C" {
 
 #define RT_ABI_VERSION 1u
 #define RT_SCENE_MAGIC 0x31535452u /* "RTS1" little endian */
+/* `const build = '741'` (main.js:3): the reference build whose per-pixel path this library reproduces, and this library's own
+ * revision of it; rt_build_id() returns "<reference build>.<revision>". */
+#define RT_REFERENCE_BUILD "741"
+#define RT_LIBRARY_REVISION "r2"
 
 #define RT_MAX_OBJECTS  256u
 #define RT_MAX_LIGHTS   16u
@@ -95,7 +99,9 @@ typedef struct rt_scene_header {
   double epsilon;          /* 0.001   main.js:430-436,445 */
   double miss_color[3];    /* [1,0,0] main.js:231 */
   uint32_t segs;           /* 8       main.js:194 */
-  uint32_t supersample;    /* 1, or 2 = render 2w x 2h and box-average 2x2 with (a+b+c+d+2)>>2 (cfg5) */
+  uint32_t supersample;    /* 1, or k in {2,3,4} = render kw x kh by the reference's rule and box-average every k x k block of RGBA8
+                            * samples with (sum + k*k/2) / (k*k), integer division: k = 2 is (a+b+c+d+2)>>2 (cfg5).  Not in the
+                            * reference: defined so that the oracle stays "main.js + an integer post-step". */
   uint32_t n_objects;      /* objs.length, already in the reference's sorted order (main.js:159-163) */
   uint32_t n_lights;       /* lights.length main.js:283 */
   uint32_t n_textures;
@@ -146,6 +152,7 @@ void rt_shutdown(void);
 int rt_device_count(void);            /* GPUs in use after rt_init, or a negative rt_status */
 const char *rt_last_error(void);
 uint32_t rt_abi_version(void);
+const char *rt_build_id(void);        /* RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION, e.g. "741.r2" (main.js:3) */
 
 /* Validate a scene blob without touching a GPU (host logic; usable in CPU-only tests). */
 int rt_scene_validate(const void *scene_blob, size_t blob_bytes);
@@ -209,6 +216,12 @@ int rt_render(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h,
 typedef void (*rt_band_callback)(void *user, uint32_t first_row, uint32_t n_rows);
 int rt_render_progressive(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, uint8_t *out_rgba,
                           uint32_t n_bands, rt_band_callback on_band, void *user, uint32_t flags, rt_stats *stats);
+
+/* The reference's end-of-frame report (main.js:204-205: `'build #' + build + ' (' + elapsed + 'ms)'`, drawn over the canvas with
+ * fillText): the same string for a finished render, with elapsed = stats->total_ms rounded to whole milliseconds as Date.now()
+ * differences are.  Writes at most cap bytes including the terminator; returns the length the full string needs (snprintf rule),
+ * or a negative rt_status. */
+int rt_elapsed_report(const rt_stats *stats, char *out, size_t cap);
 
 /* Pinned host framebuffers (the ImageData buffer of main.js:83 becomes one of these). */
 void *rt_alloc_pinned(size_t bytes);

@@ -33,10 +33,11 @@ if (cmd === 'restate' || cmd === 'reference') {
   else {
     const H = require('./ref_harness.js');
     if (!H.available()) { emit({error: 'reference not available'}); process.exit(3); }
-    if ((scene.supersample || 1) === 2) {
+    const k = scene.supersample || 1;
+    if (k > 1) {
       const plain = Object.assign({}, scene, {supersample: 1});
-      const hi = H.renderScene(plain, 2 * w, 2 * h, {row0: 2 * row0, row1: 2 * row1});
-      r = {rgba: H.boxFilter2(hi.rgba, 2 * w, 2 * (row1 - row0))};
+      const hi = H.renderScene(plain, k * w, k * h, {row0: k * row0, row1: k * row1});
+      r = {rgba: H.boxFilter(hi.rgba, k * w, k * (row1 - row0), k)};
     } else r = H.renderScene(scene, w, h, {row0, row1});
   }
   const ms = Number(process.hrtime.bigint() - t0) / 1e6;

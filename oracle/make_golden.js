@@ -41,6 +41,10 @@ const scenes = {
   default14_stars: SC.default14(tex, true),     // scene only: the reference's stars are Math.random, nothing to compare with
   lcg64: SC.lcg64(5, 2),
   lcg64_ss1: SC.lcg64(5, 1),
+  lcg64_ss3: SC.lcg64(5, 3),                    // SURVEY 8(f)-4: box supersampling beyond cfg5's 2x2
+  lcg64_ss4: SC.lcg64(5, 4),
+  default14_ss3: Object.assign(SC.default14(tex), {supersample: 3}),
+  h8_ss4: Object.assign(SC.h8(tex, 3), {supersample: 4}),
 };
 for (const [name, sc] of Object.entries(scenes)) fs.writeFileSync(path.join(SCENES, name + '.json'), F.sceneToJSON(sc, name, SCENES));
 
@@ -53,9 +57,11 @@ function frame(name, scene, w, h, rows, note) {       // store bytes
   const sc = scenes[scene];
   let rgba;
   if (rows === 'main') rgba = H.runMain(w, h);
-  else if ((sc.supersample || 1) === 2) {
-    const plain = Object.assign({}, sc, {supersample: 1});
-    rgba = H.boxFilter2(H.renderScene(plain, 2 * w, 2 * h).rgba, 2 * w, 2 * h);
+  else if ((sc.supersample || 1) > 1) {
+    const k = sc.supersample, plain = Object.assign({}, sc, {supersample: 1});
+    const hi = H.renderScene(plain, k * w, k * h).rgba;
+    rgba = k === 2 ? H.boxFilter2(hi, 2 * w, 2 * h) : H.boxFilter(hi, k * w, k * h, k);
+    if (k === 2 && Buffer.compare(Buffer.from(rgba), Buffer.from(H.boxFilter(hi, 2 * w, 2 * h, 2))) !== 0) throw new Error('boxFilter(k=2) != boxFilter2');
   } else if (rows) {
     const parts = rows.map((y) => Buffer.from(H.renderScene(sc, w, h, {row0: y, row1: y + 1}).rgba));
     rgba = Buffer.concat(parts);
@@ -89,6 +95,10 @@ frame('h8_5440x3056_rows', 'h8', 5440, 3056, [3, 1500, 1700, 2200], 'bench.py fr
 frame('h8_10848x6112_rows', 'h8', 10848, 6112, [5, 3000, 3400, 4400], 'bench.py frame at 8 GPUs, sampled rows');
 frame('lcg64_ss2_128x128', 'lcg64', 128, 128, null, 'cfg5 scene: reference at 256x256 then (a+b+c+d+2)>>2');
 frame('lcg64_ss1_192x192', 'lcg64_ss1', 192, 192, null);
+frame('lcg64_ss3_96x64', 'lcg64_ss3', 96, 64, null, 'SURVEY 8(f)-4: reference at 288x192 then (sum+4)/9 per channel');
+frame('lcg64_ss4_96x64', 'lcg64_ss4', 96, 64, null, 'SURVEY 8(f)-4: reference at 384x256 then (sum+8)>>4 per channel');
+frame('default14_ss3_67x45', 'default14_ss3', 67, 45, null, 'odd sample grid (201x135): centre row and column of the SAMPLES; refraction');
+frame('h8_ss4_131x60', 'h8_ss4', 131, 60, null, 'ragged width, 4x4 box');
 // hashes of larger frames
 hashOnly('default14_main_256x256', 'default14', 256, 256, true);
 hashOnly('default14_main_640x360', 'default14', 640, 360, true);

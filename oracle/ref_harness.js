@@ -131,7 +131,7 @@ function sameLights(scene) {
 // opts.count: also return the number of intersectWorld invocations with segs>0.
 function renderScene(scene, w, h, opts) {
   opts = opts || {};
-  if ((scene.supersample || 1) !== 1) throw new Error('oracle: render supersampled scenes at 2w x 2h and box-filter (boxFilter2)');
+  if ((scene.supersample || 1) !== 1) throw new Error('oracle: render supersampled scenes at kw x kh and box-filter (boxFilter)');
   if (scene.epsilon !== 0.001) throw new Error('oracle: the reference epsilon is the literal 0.001');
   const L = loadReference(sameLights(scene) ? {} : {lights: scene.lights, light_intensity: scene.light_intensity});
   const ref = L.ref;
@@ -174,4 +174,16 @@ function boxFilter2(rgba, w2, h2) {
   return out;
 }
 
-module.exports = {available, loadReference, runMain, renderScene, boxFilter2, REF_DIR};
+// k x k box of RGBA8 samples: (sum + k*k/2) / (k*k), integer division (k = 2 is boxFilter2's (a+b+c+d+2)>>2)
+function boxFilter(rgba, wk, hk, k) {
+  const w = wk / k, h = hk / k, kk = k * k, half = kk >> 1;
+  const out = new Uint8Array(w * h * 4);
+  for (let y = 0; y < h; y++) for (let x = 0; x < w; x++) for (let c = 0; c < 4; c++) {
+    let sum = 0;
+    for (let j = 0; j < k; j++) for (let i = 0; i < k; i++) sum += rgba[((k * y + j) * wk + k * x + i) * 4 + c];
+    out[(y * w + x) * 4 + c] = Math.floor((sum + half) / kk);
+  }
+  return out;
+}
+
+module.exports = {available, loadReference, runMain, renderScene, boxFilter2, boxFilter, REF_DIR};

@@ -26,13 +26,15 @@ function render(w, h, scene, opts) {
     return renderPlain(w, h, scene, 0, 0, opts.rows);
   }
   if (ss === 1) return renderPlain(w, h, scene, row0, row1);
-  // cfg5 supersample: 2w x 2h by the reference rule, then (a+b+c+d+2)>>2 per channel
-  const hi = renderPlain(2 * w, 2 * h, scene, 2 * row0, 2 * row1);
-  const src = hi.rgba, w2 = 2 * w, rows = row1 - row0;
+  // supersample k (2 = cfg5; 3, 4 = SURVEY 8(f)-4): kw x kh by the reference rule, then every k x k block of RGBA8 samples is
+  // averaged with (sum + k*k/2) / (k*k), integer division - for k = 2 that is (a+b+c+d+2)>>2
+  const k = ss, hi = renderPlain(k * w, k * h, scene, k * row0, k * row1);
+  const src = hi.rgba, wk = k * w, rows = row1 - row0, half = (k * k) >> 1, kk = k * k;
   const out = new Uint8Array(rows * w * 4);
   for (let y = 0; y < rows; y++) for (let x = 0; x < w; x++) for (let c = 0; c < 4; c++) {
-    const i = ((2 * y) * w2 + 2 * x) * 4 + c;
-    out[(y * w + x) * 4 + c] = (src[i] + src[i + 4] + src[i + w2 * 4] + src[i + w2 * 4 + 4] + 2) >> 2;
+    let sum = 0;
+    for (let j = 0; j < k; j++) for (let i = 0; i < k; i++) sum += src[((k * y + j) * wk + k * x + i) * 4 + c];
+    out[(y * w + x) * 4 + c] = Math.floor((sum + half) / kk);
   }
   hi.rgba = out; hi.pixels = rows * w;
   return hi;

@@ -7,7 +7,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$REPO/html5-canvas-raytracer_amd/csrc
 OUT=$REPO/build/ab; mkdir -p $OUT
 T=$(mktemp -d)
-COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -I$SRC"
+COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -mllvm -disable-machine-licm -DRT_TESTING -I$SRC"
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=0 -ffp-contract=fast -c $SRC/rt_kernel.hip -o $T/kf.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=1 -ffp-contract=off -c $SRC/rt_kernel.hip -o $T/ks.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -c $SRC/rt_api.hip -o $T/api.o &

@@ -1,17 +1,20 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py's headline workload on the GPU box.
-#   usage (from the repo root, on the box):  bash profiles/run_profile.sh <tag>     e.g. r01
+#   usage (from the repo root, on the box):  bash profiles/run_profile.sh <tag> [extra bench.py arguments]
+#   e.g.  bash profiles/run_profile.sh r02            (the default command = the headline)
+#         bash profiles/run_profile.sh r02_default14 --scene default14 --steps 600
 # Writes raw output under gpurun_out/prof_<tag>/ and the summaries to gpurun_out/profiles_<tag>/
 # (copy those into profiles/ and commit).  Counters are collected in their own passes, never
 # together with tracing (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -u
 TAG=${1:-r01}
+shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 SUM=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline"   # the default command (2000 steps, 20 warm-up), minus the CPU leg
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-pmc $*"   # the default command (2000 steps, 20 warm-up), minus the CPU leg and bench.py's own counter passes
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?" >> "$OUT/trace.log"

@@ -37,12 +37,13 @@ function maxDiff(a, b) { let m = 0; if (a.length !== b.length) return 999; for (
       seen.push([b.firstRow, b.rows]);
       worst = Math.max(worst, maxDiff(b.data, gold.subarray(b.firstRow * h8.w * 4, (b.firstRow + b.rows) * h8.w * 4)));
     }});
-    out.progressive = {bands: seen, bandDiff: worst, frameDiff: maxDiff(frame, gold), kernel_ms: frame.stats.kernel_ms};
+    out.progressive = {bands: seen, bandDiff: worst, frameDiff: maxDiff(frame, gold), kernel_ms: frame.stats.kernel_ms, report: frame.stats.report};
     // a large frame (really banded: > 8 MB) - only structure is checked here
     const big = [];
     const f2 = await rt.renderProgressive(2048, 1100, load('h8'), {bands: 8, onBand: (b) => big.push([b.firstRow, b.rows])});
     out.progressiveBig = {bands: big, length: f2.length, same: maxDiff(f2, rt.render(2048, 1100, load('h8')))};
   }
+  out.report = {build: rt.buildId(), sync: rt.render(h8.w, h8.h, load('h8')).stats, async: a.stats.report};     // main.js:3, :204-205
   const c = rt.render(h8.w, h8.h, load('h8'), {count: true});
   out.counted = {rays: c.stats.rays, pixels: c.stats.pixels};
   let threw = '';

@@ -15,10 +15,11 @@ const get = (port, p) => new Promise((resolve, reject) => {
   const out = {};
   const page = await get(port, '/');
   out.page = {status: page.status, canvas: /<canvas id='canvasID'>/.test(page.body.toString()), putImageData: /putImageData/.test(page.body.toString())};
+  out.overlay = /'build #' \+/.test(page.body.toString()) && /fillText\(message, ?0, ?0\)/.test(page.body.toString());     // main.js:205-210
   out.scenes = JSON.parse((await get(port, '/scenes')).body.toString()).scenes;
   out.bad = [(await get(port, '/frame?scene=h8&w=0&h=10')).status, (await get(port, '/frame?scene=nope&w=8&h=8')).status, (await get(port, '/frame?scene=../x&w=8&h=8')).status, (await get(port, '/other')).status];
   const f = await get(port, '/frame?scene=h8&w=240&h=135');
-  out.frame = {status: f.status, bytes: f.body.length, kernelMs: f.headers['x-kernel-ms'] || null, error: f.status === 200 ? null : JSON.parse(f.body.toString()).error};
+  out.frame = {status: f.status, bytes: f.body.length, kernelMs: f.headers['x-kernel-ms'] || null, build: f.headers['x-build'] || null, report: f.headers['x-report'] || null, error: f.status === 200 ? null : JSON.parse(f.body.toString()).error};
   if (f.status === 200) {
     const gold = fs.readFileSync(path.join(ROOT, 'tests', 'golden', 'h8_240x135.rgba'));
     let m = 0; for (let i = 0; i < gold.length; i++) m = Math.max(m, Math.abs(gold[i] - f.body[i]));
@@ -26,7 +27,7 @@ const get = (port, p) => new Promise((resolve, reject) => {
   }
   // the chunked, progressive form of the same frame
   const g = await get(port, '/frame?scene=h8&w=240&h=135&progressive=5');
-  out.progressive = {status: g.status, bytes: g.body.length, chunked: g.headers['transfer-encoding'] || null, kernelMs: (g.trailers || {})['x-kernel-ms'] || null,
+  out.progressive = {status: g.status, bytes: g.body.length, chunked: g.headers['transfer-encoding'] || null, kernelMs: (g.trailers || {})['x-kernel-ms'] || null, build: g.headers['x-build'] || null, report: (g.trailers || {})['x-report'] || null,
     error: g.status === 200 ? null : JSON.parse(g.body.toString()).error};
   if (g.status === 200) out.progressive.sameAsWhole = Buffer.compare(g.body, f.body) === 0;
   server.close();

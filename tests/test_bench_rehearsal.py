@@ -1,0 +1,100 @@
+"""bench.py's N>1 control flow, rehearsed on the ONE-GPU box (run with -m gpu): two ranks share GPU 0 and talk over gloo through
+host memory (RT_BENCH_REHEARSE=1), started as fresh child processes by torch.distributed.run before anything touches the GPU.
+Never a measurement - the JSON line says so - but every plan's set-up, pre-flight, fallback, calibration, steady-state loop,
+pipelining and parity check runs exactly as on a multi-GPU node, and the peer-store plan really crosses a process boundary
+(IPC handles between the two ranks).  The first real xGMI run is then not a debugging session."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import oracle_util as ou
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_bench(world, extra_args=(), **env_extra):
+    env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ou.ROOT, "bench.py"), "--gpus", str(world), "--steps", "10", "--warmup", "2", *extra_args]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 10 and out["warmup"] == 2
+    assert out["parity_ok"] is True and out["max_lsb_vs_reference_rows"] <= 1
+    assert "REHEARSAL" in out["config"]
+    assert out["config"]["steady_state_warmup"]["trains"] >= 2
+    return out, r.stderr
+
+
+def test_batch_mode_exchange_plan():
+    """cfg3 at N=2: a batch of 2 frames per step, RGB24 bands, one all-to-all per 4 steps, frame f whole on rank f."""
+    out, _ = run_bench(2)
+    assert out["scaling"] == "weak" and out["config"]["frames_per_step"] == 2
+    assert out["exchange"]["collective"] == "all_to_all_single" and out["exchange"]["bytes_per_pixel_on_the_link"] == 3
+    assert out["exchange"]["steps_per_collective"] == 4
+    assert "plan_calibration_ms_per_step" not in out["config"]
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+
+
+def test_batch_mode_peer_store_plan():
+    """RT_BENCH_P2P=1: every rank's kernel stores its tiles straight into the owning rank's frame buffer, opened through an IPC
+    handle from the OTHER process; the pre-flight frame matches the reference's rows."""
+    out, _ = run_bench(2, RT_BENCH_P2P="1")
+    assert out["exchange"]["plan"].startswith("peer stores")
+    assert "plan_note" not in out["config"]
+    assert out["exchange"]["bytes_stored_remotely_per_rank_per_step"] > 0
+
+
+def test_peer_store_failure_falls_back_to_the_exchange_plan():
+    out, err = run_bench(2, RT_BENCH_P2P="1", RT_BENCH_P2P_INJECT_FAILURE="1")
+    assert "injected failure on rank 1" in out["config"]["plan_note"]
+    assert out["exchange"]["collective"] == "all_to_all_single"
+    assert "peer-store plan not usable" in err
+
+
+def test_auto_calibration_times_both_plans():
+    out, _ = run_bench(2, RT_BENCH_P2P="auto")
+    cal = out["config"]["plan_calibration_ms_per_step"]
+    assert set(cal) == {"exchange", "peer_stores"} and all(v > 0 for v in cal.values())
+    chosen_p2p = out["exchange"]["plan"].startswith("peer stores")
+    assert chosen_p2p == (cal["peer_stores"] <= cal["exchange"])
+
+
+@pytest.mark.parametrize("p2p", ["0", None])
+def test_cfg4_one_frame_row_tiled_over_the_ranks(p2p):
+    """BASELINE configs[3] as stated: ONE 7680x4320 frame per step, row-tiled over the ranks, whole on rank 0 after one gather
+    (RT_BENCH_P2P=0) or - default - after whichever of the two plans the calibration finds faster; checked against the rows
+    the reference itself rendered (tests/golden/h8_7680x4320_rows)."""
+    env = {} if p2p is None else {"RT_BENCH_P2P": p2p}
+    out, _ = run_bench(2, ("--config", "cfg4"), **env)
+    assert out["scaling"] == "strong" and out["config"]["frames_per_step"] == 1
+    assert out["config"]["workload"].startswith("cfg4: h8 scene") and "7680x4320" in out["config"]["workload"]
+    assert "h8_7680x4320_rows" in out["parity_checked_against"]
+    if p2p == "0":
+        assert out["exchange"]["collective"] == "gather to rank 0"
+    else:
+        assert set(out["config"]["plan_calibration_ms_per_step"]) == {"exchange", "peer_stores"}
+
+
+def test_cfg5_scene_single_frame_mode_at_reduced_size():
+    """BASELINE configs[4]'s scene and mode (one supersampled frame per step, 64 spheres, depth 5, whole on rank 0) at 2048x2048
+    so that the rehearsal stays short; a frame size without golden rows is checked against the C restatement's rows."""
+    out, _ = run_bench(3, ("--config", "cfg5", "--width", "2048", "--height", "2048"), RT_BENCH_P2P="auto")
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong"
+    assert "oracle/rt_oracle.c rows" in out["parity_checked_against"]
+    assert "supersample 2" in out["config"]["workload"]

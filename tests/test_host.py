@@ -275,3 +275,20 @@ def test_bounce_table_is_conservative(built):
         listed += sum(mask)
     assert checked == 1500 and hits > 3000
     assert listed < 0.75 * checked * n                    # and it does prune (the two giant spheres are always listed)
+
+
+def test_build_stamp_and_elapsed_report(built):
+    """`const build = '741'` (main.js:3) and the end-of-frame string 'build #' + build + ' (' + elapsed + 'ms)'
+    (main.js:204-205), elapsed a whole number of milliseconds as a Date.now() difference is."""
+    import re
+    lib = rt_host.load_library()
+    assert re.fullmatch(r"741\.r\d+", rt_host.build_id(lib))
+    st = rt_host.RtStats()
+    for ms, shown in [(0.0, 0), (0.49, 0), (12.5, 13), (19490.2, 19490), (-3.0, 0)]:
+        st.total_ms = ms
+        assert rt_host.elapsed_report(st, lib) == "build #%s (%dms)" % (rt_host.build_id(lib), shown)
+    import ctypes as C
+    assert lib.rt_elapsed_report(None, C.create_string_buffer(8), 8) == -1
+    small = C.create_string_buffer(8)
+    st.total_ms = 7.0
+    assert lib.rt_elapsed_report(C.byref(st), small, 8) == len("build #%s (7ms)" % rt_host.build_id(lib)) and small.value == b"build #"    # snprintf rule

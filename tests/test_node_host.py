@@ -20,13 +20,14 @@ def test_addon_loads_and_fails_loudly_without_gpu(built):
 const rt = require('%s/js/index.js'); const F = require('%s/js/flatten.js'); const fs = require('fs');
 const n = rt.native();
 const sc = F.sceneFromJSON(fs.readFileSync('%s/scenes/cfg1.json', 'utf8'), '%s/scenes');
-const out = {exports: Object.keys(n).sort(), abi: n.abiVersion(), valid: n.validate(rt.flattenScene(sc)), err: ''};
+const out = {exports: Object.keys(n).sort(), abi: n.abiVersion(), build: rt.buildId(), valid: n.validate(rt.flattenScene(sc)), err: ''};
 try { rt.render(16, 16, sc); out.err = 'rendered'; } catch (e) { out.err = e.message; }
 console.log(JSON.stringify(out));
 """ % (PKG, PKG, PKG, PKG)
     out = json.loads(subprocess.check_output([ou.node_path(), "-e", js], text=True))
-    assert out["exports"] == ["abiVersion", "init", "render", "renderAsync", "renderProgressive", "shutdown", "validate"]
+    assert out["exports"] == ["abiVersion", "buildId", "init", "render", "renderAsync", "renderProgressive", "shutdown", "validate"]
     assert out["abi"] == 1 and out["valid"] is True
+    assert out["build"].startswith("741.")                 # `const build = '741'` (main.js:3) + the library's revision
     import torch
     if not torch.cuda.is_available():
         assert "no HIP device" in out["err"]
@@ -54,6 +55,13 @@ def test_node_render_matches_reference_frames(built):
     assert len(big["bands"]) == 8 and sum(r for _, r in big["bands"]) == 1100 and [f for f, _ in big["bands"]] == sorted(f for f, _ in big["bands"])
     assert out["counted"]["pixels"] == 240 * 135 and out["counted"]["rays"] > out["counted"]["pixels"]
     assert "sampler" in out["unsupported"]
+    # the build stamp and the reference's end-of-frame report (main.js:3, :204-205) on every render's stats
+    import re
+    rep = out["report"]
+    assert re.fullmatch(r"741\.r\d+", rep["build"]) and rep["sync"]["build"] == rep["build"]
+    for text in (rep["sync"]["report"], rep["async"], out["progressive"].get("report")):
+        assert re.fullmatch(r"build #741\.r\d+ \(\d+ms\)", text), text
+    assert rep["sync"]["report"] == "build #%s (%dms)" % (rep["build"], round(rep["sync"]["total_ms"]))
 
 
 def _run_server_check():
@@ -69,6 +77,7 @@ def test_http_bridge_surface(built):
     never a CPU-rendered frame."""
     out = _run_server_check()
     assert out["page"] == {"status": 200, "canvas": True, "putImageData": True}
+    assert out["overlay"] is True                   # the page draws 'build #<id> (<elapsed>ms)' at (0,0) like main.js:205-210
     assert "h8" in out["scenes"] and "default14" in out["scenes"]
     assert out["bad"] == [400, 404, 400, 404]
     import torch
@@ -86,3 +95,6 @@ def test_http_bridge_serves_reference_frame(built):
     pr = out["progressive"]          # chunked response, one chunk per band, timings as trailers
     assert pr["status"] == 200 and pr["bytes"] == 240 * 135 * 4 and pr["chunked"] == "chunked"
     assert pr["sameAsWhole"] and float(pr["kernelMs"]) > 0
+    import re
+    assert re.fullmatch(r"741\.r\d+", out["frame"]["build"]) and pr["build"] == out["frame"]["build"]
+    assert re.fullmatch(r"build #741\.r\d+ \(\d+ms\)", out["frame"]["report"]) and re.fullmatch(r"build #741\.r\d+ \(\d+ms\)", pr["report"])
