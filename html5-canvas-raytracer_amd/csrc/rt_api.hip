@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(256) rt_box_filter_kernel(const rt_box_launch 
 
 // supersample 3 and 4: the k*w x k*h sample frame of this call's tiles is rendered by the ordinary launch
 // (supersample 1 on the sample grid: same kernels, same centre-row/column rule, same tiles with k times the rows) into
-// stream-ordered scratch memory, in pieces of at most ~512 MiB, and box-filtered into the caller's output.
+// scratch memory, in pieces of at most ~512 MiB, and box-filtered into the caller's output.
 int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, const rt_tiles *tiles, uint32_t n_frames, void *d_out, uint64_t frame_stride_bytes,
                         void *const *d_frames, hipStream_t stream, uint32_t flags, rt_stats *stats) {
   if (flags & RT_FLAG_RGB24) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 needs supersample 1 or 2 (the %ux%u box filter stores RGBA8)", k, k);
@@ -795,9 +795,7 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
       const uint32_t band_rows = po.n_tiles * po.tile_rows;
       const size_t frame_words = (size_t)band_rows * k * w * k;
       void *scratch = nullptr;
-      bool pooled = true;
-      hipError_t e = hipMallocAsync(&scratch, frame_words * 4u * n_frames, stream);
-      if (e != hipSuccess) { (void)hipGetLastError(); pooled = false; e = hipMalloc(&scratch, frame_words * 4u * n_frames); }
+      hipError_t e = hipMalloc(&scratch, frame_words * 4u * n_frames);
       if (e != hipSuccess) return fail(RT_ERR_NOMEM, "supersample scratch (%zu bytes): %s", frame_words * 4u * n_frames, hipGetErrorString(e));
 #ifdef RT_TESTING
       (void)hipMemsetAsync(scratch, 0xA5, frame_words * 4u * n_frames, stream);      // test build: a sample nobody writes shows up as 0xA5, not as stale data
@@ -819,8 +817,8 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
         e = hipGetLastError();
         if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "box filter launch: %s", hipGetErrorString(e));
       }
-      if (pooled) e = hipFreeAsync(scratch, stream);
-      else { (void)hipStreamSynchronize(stream); e = hipFree(scratch); }
+      (void)hipStreamSynchronize(stream);            // (a 9x / 16x render: the allocation and this wait are noise beside it)
+      e = hipFree(scratch);
       if (rc) return rc;
       if (e != hipSuccess) return fail(RT_ERR_DEVICE, "supersample scratch release: %s", hipGetErrorString(e));
       if (stats) { agg.kernel_ms += st.kernel_ms; agg.rays += st.rays; agg.shadow_rays += st.shadow_rays; agg.sphere_tests += st.sphere_tests; }

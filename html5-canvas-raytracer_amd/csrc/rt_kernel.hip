@@ -948,6 +948,9 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
   const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
+#if !RT_STRICT
+  if (P0.rows_valid == 0u) return;                     // workgroup-uniform: a block wholly past its tile's or the frame's last row
+#endif
   const uint32_t px = P0.px, frow = P0.frow, sub = P0.sub;
   const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px;
   const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
