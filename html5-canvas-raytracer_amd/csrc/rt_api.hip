@@ -115,6 +115,9 @@ struct rt_scene_dev {
   unsigned lds_bytes;
   double lights[RT_MAX_LIGHTS][3];   // host copy: lights travel in the kernarg segment
   uint32_t enclosing;            // sphere that strictly contains everything else (a skybox), or ~0u
+  bool enclosing_flat;           // ... and it has no lighting, no children and a sampler that ignores the hit point (colour / stars)
+  bool sky_const;                // ... a plain colour: the pixel of a ray that meets nothing else is the constant sky_rgb
+  double sky_rgb[3];
   // cost-ordered dispatch (dispatch_order below): per sphere its screen rectangle (X/D, Y/D bounds, scene order) and a weight,
   // and the order tables built so far, one per (frame size, tile set), kept on the device
   std::vector<rt_geom> host_cull;
@@ -472,6 +475,24 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     for (uint32_t j = 0; j < hd->n_objects && ok; j++) if (j != e) ok = dist_to(ob[j].origin) + sqrt(ob[j].r2) < lim;
     if (ok && hd->n_objects > 1) s->enclosing = e;
   }
+  s->enclosing_flat = false;
+  if (s->enclosing != ~0u) {
+    const rt_sphere &sk = ob[s->enclosing];
+    s->enclosing_flat = !(sk.albedo[1] > 0.0) && !(sk.albedo[2] > 0.0) && !(sk.albedo[3] > 0.0) && !(sk.albedo[4] > 0.0) &&
+                        (sk.sampler_kind == RT_SAMPLER_COLOR || sk.sampler_kind == RT_SAMPLER_STARS);
+  }
+  s->sky_const = s->enclosing_flat && ob[s->enclosing].sampler_kind == RT_SAMPLER_COLOR && hd->segs > 0;
+  for (int c = 0; c < 3; c++) {
+    s->sky_rgb[c] = 0.0;
+    if (s->sky_const) {
+      // main.js:322-336 for a hit without light and without children: diffuse = specular = 0, reflect = refract = [0,0,0]
+      const volatile double col = ob[s->enclosing].color[c], a0 = ob[s->enclosing].albedo[0], zero = 0.0;
+      const volatile double amb = col * a0, d0 = col * zero, s0 = col * zero;
+      const volatile double shade = d0 + s0;
+      const double m1 = (shade > 1.0) ? 1.0 : shade;                    // Math.min(1, shade); NaN stays NaN
+      s->sky_rgb[c] = (m1 < amb) ? (double)amb : m1;                    // Math.max(amb, .) as the kernel's maxa() evaluates it
+    }
+  }
   // cost-ordered dispatch: what a tile that shows sphere j is expected to cost, in rough units of one shaded hit - a guess
   // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
   // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
@@ -652,7 +673,8 @@ namespace {
 // them dearest first, so the launch ends on sky.  Every tile is still rendered exactly once by exactly one workgroup: the
 // picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
 const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked) {
+                           double proj_w, double proj_h, double proj_d, bool ranked, bool *temporary) {
+  *temporary = false;
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
   if (tiles_x > 2048u || n64 >= (1ull << 31)) { fail(RT_ERR_INVALID, "launch of %llu workgroups is beyond the launch table", (unsigned long long)n64); return nullptr; }
@@ -696,7 +718,8 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
     for (uint32_t c : cost) start[cmax - c + 1u]++;
     for (uint32_t c = 0; c <= cmax; c++) start[c + 1u] += start[c];
   }
-  std::vector<uint32_t> table((size_t)n * 2u);
+  const uint32_t n8 = (n + 7u) / 8u;                    // workgroup b's entry sits at (b % 8) * n8 + b / 8: one contiguous part per XCD
+  std::vector<uint32_t> table((size_t)n8 * 8u * 2u, 0u);
   uint32_t next = 0;
   for (uint32_t y = 0; y < ny; y++) {
     const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
@@ -711,19 +734,19 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
     const uint32_t w0 = (rows_valid << 11) | ((uint32_t)(frow0 < h ? frow0 : 0u) << 15);        // frow0 < 65536 + 8: 17 bits
     const uint32_t w1 = tile_i * tiles->tile_rows + trow0;
     for (uint32_t x = 0; x < tiles_x; x++) {
-      const uint32_t at = rank ? start[cmax - cost[(size_t)y * tiles_x + x]]++ : next++;
-      table[2u * (size_t)at] = w0 | x; table[2u * (size_t)at + 1u] = w1;
+      const uint32_t b = rank ? start[cmax - cost[(size_t)y * tiles_x + x]]++ : next++;      // the workgroup that renders this tile
+      const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
+      table[2u * at] = w0 | x; table[2u * at + 1u] = w1;
     }
   }
   uint32_t *d = nullptr;
-  hipError_t e = hipMalloc((void **)&d, (size_t)n * 8u);
-  if (e == hipSuccess) e = hipMemcpy(d, table.data(), (size_t)n * 8u, hipMemcpyHostToDevice);
+  hipError_t e = hipMalloc((void **)&d, table.size() * 4u);
+  if (e == hipSuccess) e = hipMemcpy(d, table.data(), table.size() * 4u, hipMemcpyHostToDevice);
   if (e != hipSuccess) { if (d) (void)hipFree(d); fail(RT_ERR_DEVICE, "launch table: %s", hipGetErrorString(e)); return nullptr; }
-  if (s->orders.size() >= 8u) {                        // the oldest table may still be read by a launch in flight: drain the device first
-    (void)hipDeviceSynchronize();
-    (void)hipFree(s->orders.front().d_order);
-    s->orders.erase(s->orders.begin());
-  }
+  // A cached table is never freed while the scene lives (another thread may be about to launch with it); a scene that has
+  // been rendered with 64 different (frame size, tile set) pairs gets per-call tables from then on, freed by the caller once
+  // its launches have drained.
+  if (s->orders.size() >= 64u) { *temporary = true; return d; }
   s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, d});
   return d;
 }
@@ -888,6 +911,9 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     K.bounce_table = (!plain && !no_bounce) ? s->d_bounce_table : nullptr;
     K.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
     K.enclosing = order_b ? hd.n_objects - 1 : ~0u;
+    K.enclosing_flat = (order_b && s->enclosing_flat) ? 1u : 0u;
+    K.sky_fast = (K.enclosing_flat && s->sky_const) ? 1u : 0u;
+    for (int c = 0; c < 3; c++) K.sky_rgb[c] = s->sky_rgb[c];
   };
   auto lds_for = [&](bool strict) {
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
@@ -937,9 +963,16 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
   static const bool no_order = RT_TEST_ENV("RT_NO_DISPATCH_ORDER") != nullptr;    // A/B switch (test build): the grid's own order
+  struct table_guard {                                   // a per-call launch table is released on every way out, after the stream has drained
+    void *p = nullptr; hipStream_t st = nullptr;
+    ~table_guard() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
+  } temp_table;
   if (!strict_main) {
-    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order);
+    bool temporary = false;
+    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, &temporary);
     if (!L.order) return RT_ERR_DEVICE;
+    if (temporary) { temp_table.p = (void *)L.order; temp_table.st = stream; }
+    L.order_n8 = (L.tiles_x * tiles->n_tiles * L.rb_per_tile + 7u) / 8u;
   }
   int err = (strict_main ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, lds_for(strict_main), stream);
   // Centre row / centre column of a sample grid with an ODD number of rows / columns.  The primary rays there have a direction

@@ -62,6 +62,9 @@ struct rt_launch {
   uint32_t n_loop;                   // spheres the per-ray loops walk (n_objects, or n_objects-1 when `enclosing` is set)
   uint32_t enclosing;                // device index (== n_loop, the table's last entry) of a sphere that strictly contains
                                      // every other sphere, every light and the camera; ~0u if none or not used
+  uint32_t sky_fast;                 // ... and its colour is a constant: a wave whose primary rays all miss the loop spheres stores sky_rgb
+  double sky_rgb[3];
+  uint32_t enclosing_flat;           // that sphere neither lights nor spawns rays and its colour ignores the hit point: its test is skipped
   uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
@@ -70,6 +73,7 @@ struct rt_launch {
   // entry b = {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band}; the host lists the tiles
   // dearest first, so that a launch ends on cheap tiles.  The strict kernel runs on the plain 2-D grid and ignores it.
   const uint32_t *order;
+  uint32_t order_n8;                 // ceil(workgroups / 8): entry of workgroup b sits at (b % 8) * order_n8 + b / 8 (one contiguous part per XCD)
   // Fix-up launches (strict kernel only, rt_api.hip render_batch_impl): the grid starts at workgroup (bx0, by0) and only the
   // pixels of the window [win_x0, win_x0 + win_w) x [win_y0, win_y0 + win_h) (frame coordinates) are stored.
   uint32_t bx0, by0, win_x0, win_w, win_y0, win_h;

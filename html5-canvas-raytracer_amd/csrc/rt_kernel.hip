@@ -13,10 +13,12 @@
 //
 // MI355X mapping (no MFMA: there is no dense contraction anywhere in this path; all arithmetic is
 // binary64 VALU, which is what JS numbers are):
-//   * one work-item per pixel (per SAMPLE when supersampling); a wave owns a compact 8x8 block so its
+//   * one work-item per pixel (per SAMPLE when supersampling 2x2); a wave owns a compact 8x8 block so its
 //     64 rays take the same branches; 4 waves side by side make a 32x8 workgroup tile = whole
 //     128-byte framebuffer lines, each line written by exactly one workgroup (no cross-XCD sharing);
-//     grid = (tiles across, tiles x row blocks, frames of the batch): no integer division in the kernel;
+//     product kernel: a FLAT grid whose workgroups look their tile up in a host-built launch table (one
+//     s_load_dwordx2: no tile arithmetic, no division) that lists the tiles dearest first, so a launch ends
+//     on cheap sky tiles (rt_api.hip: dispatch_order); strict kernel: the plain 2-D grid;
 //   * everything wave-uniform — camera, lights, loop bounds (kernarg) and the sphere tables walked by
 //     the uniform object loops (typed address_space(4)) — is read with SCALAR loads into SGPRs: the
 //     intersection loops issue no vector memory and no LDS instruction;
@@ -35,7 +37,13 @@
 //
 // The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (the product kernel)
 // and RT_STRICT=1 with -ffp-contract=off (operation for operation with the JS expression trees, IEEE
-// sqrt/div, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB.
+// sqrt/div, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB on generic
+// samples.  Samples whose outcome in the reference is decided by the last bit of its own arithmetic - rays
+// with an exactly-zero direction component (the centre row / column of an odd sample grid) that stay in a
+// coordinate plane through sphere centres, a light exactly on a surface - can only be reproduced by the
+// reference's own operation sequence: the library renders those with the strict kernel (rt_api.hip:
+// render_batch_impl's fix-up launches, rt_scene_dev::needs_strict), which is why the strict build takes a
+// window and a grid offset.
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -154,6 +162,77 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
 }
 #endif
 
+// ---- atan2 / asin for the samplers (main.js:127-128, 446-447) --------------------------------------------------------
+// RT_STRICT: OCML's.  Product kernel: the same argument reductions and minimax polynomials (atan: odd polynomial of degree 39
+// on [0,1] after q = min/max; asin: x + x*r*P(r), r = x^2 below 1/2 and (1-|x|)/2 above with pi/2 - 2*asin(sqrt(r))), but
+//   * every Horner step is ONE v_fma_f64 whose constant comes from an SGPR pair (hipcc otherwise writes the 64-bit literal
+//     into the v_fmac accumulator with two v_mov_b32 per step: 64 of OCML's ~230 instructions for the pair of calls),
+//   * the quotient is the kernel's rcp + Newton division, the square root its rsq + Newton one,
+//   * the branch above 1/2 finishes in working precision instead of OCML's double-double tail.
+// Accuracy: <= 2 ulp (OCML: <= 1); what the samplers make of it is a texel index / a checker parity, i.e. the same last-ulp
+// sensitivity at boundaries that OCML, glibc and V8 already have among themselves (the one listed
+// exception); the parity suite and the soaks hold the result to 1 LSB.
+#if RT_STRICT || (defined(RT_TESTING) && defined(RT_AB_OCML_TRIG))
+__device__ __forceinline__ double rt_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ double rt_asin(double x) { return asin(x); }
+#else
+__device__ __forceinline__ double rt_fma_k(double a, double b, double k) {     // a*b + k, k wave-uniform: v_fma_f64 v, v, v, s[..]
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+}
+// the polynomial coefficients (OCML's, as 64-bit patterns): a table in constant memory, read with scalar loads - an s_load_dwordx16
+// brings eight of them into SGPRs with ONE scalar instruction, where immediates would take two s_mov_b32 each (the scalar unit
+// is shared by the CU's four SIMDs and is ~60 % busy in this kernel: measured, immediates made the kernel slower)
+__constant__ unsigned long long RT_TRIG_BITS[32] = {
+    // atan: c0 .. c19, highest degree first
+    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull, 0x3f7d6d43a595c56full, 0xbf8c6ea4a57d9582ull,
+    0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull, 0x3fa2c15b5711927aull, 0xbfa59976e82d3ff0ull, 0x3fa82d5d6ef28734ull, 0xbfaae5ce6a214619ull,
+    0x3fae1bb48427b883ull, 0xbfb110e48b207f05ull, 0x3fb3b13657b87036ull, 0xbfb745d119378e4full, 0x3fbc71c717e1913cull, 0xbfc2492492376b7dull,
+    0x3fc99999999952ccull, 0xbfd5555555555523ull,
+    // asin: c0 .. c11
+    0x3fa059859fea6a70ull, 0xbf90a5a378a05eafull, 0x3f94052137024d6aull, 0x3f7ab3a098a70509ull, 0x3f88ed60a300c8d2ull, 0x3f8c6fa84b77012bull,
+    0x3f91c6c111dccb70ull, 0x3f96e89f0a0adacfull, 0x3f9f1c72c668963full, 0x3fa6db6db41ce4bdull, 0x3fb333333336fd5bull, 0x3fc5555555555380ull};
+typedef const double __attribute__((address_space(4))) *rt_trig_kptr;
+__device__ __forceinline__ rt_trig_kptr rt_trig_table() {
+  rt_trig_kptr t = (rt_trig_kptr)(const void *)RT_TRIG_BITS;
+  asm volatile("" : "+s"(t));                        // opaque: the reads below stay scalar LOADS instead of being folded back into immediates
+  return t;
+}
+__device__ __forceinline__ double rt_atan2(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  const double hi = __builtin_fmax(ax, ay), lo = __builtin_fmin(ax, ay);
+  const double q = rt_div(lo, hi);                                   // in [0,1]; 0/0 (both zero) handled below
+  const double z = q * q;
+  const rt_trig_kptr K = rt_trig_table();
+  double p = K[0];
+#pragma unroll
+  for (uint32_t i = 1; i < 20; i++) p = rt_fma_k(p, z, K[i]);
+  double a = __builtin_fma(q, z * p, q);                             // atan(q), q in [0,1]
+  a = (ay > ax) ? (M_PI / 2.0 - a) : a;
+  const bool xneg = (__builtin_bit_cast(unsigned long long, x) >> 63) != 0;      // the sign BIT: atan2(+-0, -0) = +-pi
+  a = xneg ? (M_PI - a) : a;
+  a = (hi == 0.0) ? (xneg ? M_PI : 0.0) : a;                         // atan2(+-0, +-0)
+  return __builtin_copysign(a, y);                                   // NaN in, NaN out (every step above propagates it)
+}
+__device__ __forceinline__ double rt_asin(double x) {
+  const double y = __builtin_fabs(x);
+  const double t = __builtin_fma(y, -0.5, 0.5);                      // (1 - |x|) / 2
+  const bool big = (y >= 0.5);
+  const double r = big ? t : x * x;
+  const rt_trig_kptr K = rt_trig_table();
+  double p = K[20];
+#pragma unroll
+  for (uint32_t i = 21; i < 32; i++) p = rt_fma_k(p, r, K[i]);
+  p = p * r;
+  const double s = big ? rt_sqrt_nn(t) : y;
+  const double w = __builtin_fma(s, p, s);                           // asin(s)
+  double a = big ? __builtin_fma(-2.0, w, M_PI / 2.0) : w;
+  a = (y > 1.0) ? __builtin_nan("") : a;                             // |x| > 1 by an ulp (a ray through the exact pole): NaN, as Math.asin gives
+  return __builtin_copysign(a, x);
+}
+#endif
+
 // main.js:40-43 — v + n * (-(2 * v.n))
 __device__ __forceinline__ v3 reflect(const v3 v, const v3 n) {
   const double t = -(2.0 * dot(v, n));
@@ -190,11 +269,13 @@ __device__ __forceinline__ uint32_t to_byte(double c) {
   // value; v_rndne_f64 rounds half to even.
   return (uint32_t)__builtin_rint(__builtin_fmin(__builtin_fmax(255.0 * c, 0.0), 255.0));
 #else
-  // Three operations instead of five: clamp c itself to [0,1] (fmax(NaN, 0) = 0), then ONE fma adds 255*c to 1.5*2^52, whose
-  // ulp is 1: the sum's low mantissa word IS the byte, rounded half to even by the fma's own rounding - of the exact product,
-  // where the reference rounds fl(255*c); the two differ only when fl(255*c) lands exactly on k + 1/2 and 255*c does not
-  // (~2^-45 of the values), and then by the 1 LSB the product kernel is allowed.
-  const double s = __builtin_fma(__builtin_fmin(__builtin_fmax(c, 0.0), 1.0), 255.0, 6755399441055744.0);
+  // Four operations instead of five: the product is rounded to binary64 FIRST, exactly as the reference's `255 * rgb[c]` is
+  // (main.js:195) - values of the form k + 1/2 are common there (0.04 % of all channels: 255 * (j/255) / 2 ...) and the store's
+  // round-half-to-even must see them as the ties they are - then clamped, and ONE addition onto 1.5*2^52 (whose ulp is 1) does
+  // the rounding to nearest-even and leaves the byte in the sum's low mantissa word (v_rndne + v_cvt in one operation).
+  // (Folding the multiplication into that addition as an fma would round the EXACT product instead: measured 1.7e-4 of all
+  // channels off by one against 4e-7, profiles/r02_ab_log.md.)
+  const double s = __builtin_fmin(__builtin_fmax(255.0 * c, 0.0), 255.0) + 6755399441055744.0;
   return (uint32_t)__builtin_bit_cast(unsigned long long, s);
 #endif
 }
@@ -258,7 +339,10 @@ template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   typedef const unsigned long long __attribute__((address_space(4))) *order_kptr;
-  const unsigned long long e64 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)blockIdx.x << 3));   // s_load_dwordx2
+  // entry of workgroup b at (b % 8) * ceil(n / 8) + b / 8: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+  // correctness), so each XCD's L2 reads one contiguous eighth of the table instead of every line of it
+  const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
+  const unsigned long long e64 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 3));   // s_load_dwordx2
   const uint32_t e0 = (uint32_t)e64, e1 = (uint32_t)(e64 >> 32);
   const uint32_t tile_x = e0 & 2047u, rows_valid = (e0 >> 11) & 15u, frow0 = e0 >> 15;
   rt_pixel P;
@@ -395,6 +479,16 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         }
   }
   bool searched = true;                // the primary ray's candidates were found above (culled; camera-anchored in the product kernel)
+#if !RT_STRICT
+  // A wave none of whose primary rays met a sphere of the loops, in a scene whose enclosing sphere is flat AND constant in colour
+  // (the reference's skybox with a plain colour): every pixel of the wave is that sphere's ambient term, max(color*albedo[0],
+  // min(1, color*0 + color*0)) (main.js:326-336 with no light and no child), which the host evaluated once.  Nothing else runs.
+  if (L.sky_fast && segs_left != 0 && __ballot(hcode >= 0) == 0ull) {
+    if (COUNT) { cnt[0]++; cnt[2] += N; }
+    rgb[0] = L.sky_rgb[0]; rgb[1] = L.sky_rgb[1]; rgb[2] = L.sky_rgb[2];
+    return;
+  }
+#endif
 
   if (segs_left != 0) {
     for (;;) {
@@ -461,8 +555,15 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // kept LAST in the device tables and outside the loops above: it can only be the closest hit of a
       // ray that hits nothing else.  Only the lanes still without a hit evaluate it.
       if (enc != ~0u && hcode < 0) {
-        const rt_geom g0 = RT_LOAD(geom, enc);
-        RT_GENERIC(enc, g0)
+        if (L.enclosing_flat) {
+          // ... and when that sphere is flat - no lighting, no children, a colour that does not depend on the hit point (the
+          // reference's skybox: albedo [1,0,0,0,0], main.js:124) - WHERE the ray meets it does not matter: a ray that starts
+          // strictly inside it always does (main.js:429-439 returns t1 > 0.001), so the test is not evaluated at all
+          ht = 1.0; hcode = (int)(2u * enc + 1u);
+        } else {
+          const rt_geom g0 = RT_LOAD(geom, enc);
+          RT_GENERIC(enc, g0)
+        }
       }
 #undef RT_ANCHORED
 #undef RT_GENERIC
@@ -509,8 +610,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const int kind = m.sampler_kind;
 #endif
         if (kind == RT_SAMPLER_TEXTURE) {
-          const double u = RT_DIV_CONST(atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
-          const double v = RT_DIV_CONST(asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
+          const double u = RT_DIV_CONST(rt_atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
+          const double v = RT_DIV_CONST(rt_asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
           const rt_texture_desc td = tex[m.texture];
           const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
           uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
@@ -520,8 +621,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
           if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
         } else if (kind == RT_SAMPLER_CHECKER) {
-          const double u = RT_DIV_CONST(atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
-          const double v = RT_DIV_CONST(asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
+          const double u = RT_DIV_CONST(rt_atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
+          const double v = RT_DIV_CONST(rt_asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
           col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
         } else if (kind == RT_SAMPLER_STARS) {

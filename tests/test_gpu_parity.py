@@ -2,7 +2,11 @@
 C ABI (librt_hip.so -> HIP kernel); the oracle is only the checker.
 
 Tolerance: <= 1 LSB per channel against the reference (SURVEY §8(c) tolerance ladder: the path is
-binary64; the only admissible differences are exact-.5 rounding ties moved by an ulp).
+binary64; the only admissible differences are exact-.5 rounding ties moved by an ulp).  What that takes beyond a
+binary64 kernel is pinned here too: samples whose outcome in the reference hinges on an exact coincidence (centre row /
+column of an odd sample grid, a light on a surface) are rendered by the operation-for-operation kernel
+(test_soak_seeds_on_exact_coincidences, test_centre_row_and_column_come_from_the_strict_kernel), and the one known
+pixel where OCML and libm part by an ulp on a discontinuity is listed (test_the_one_intrinsic_exception_ocml_vs_libm).
 """
 import ctypes as C
 import math
@@ -257,7 +261,8 @@ def test_strict_and_fma_kernels_agree_within_1_lsb_at_4k(lib):
     assert worst <= 1 and frac < 0.01
 
 
-@pytest.mark.parametrize("variant", ["light_outside", "reflective_sky", "camera_outside", "nested_skies", "sky_not_last"])
+@pytest.mark.parametrize("variant", ["light_outside", "reflective_sky", "camera_outside", "nested_skies", "sky_not_last", "coloured_flat_sky",
+                                     "textured_sky", "negative_flat_sky"])
 def test_enclosing_sphere_shortcut_is_exact(lib, variant):
     """The product kernel takes a sphere that strictly contains everything (a skybox) out of its per-ray
     loops.  Scenes where the premise holds, barely fails, or holds for a shaded / reflective sphere."""
@@ -274,11 +279,23 @@ def test_enclosing_sphere_shortcut_is_exact(lib, variant):
     elif variant == "nested_skies":
         s["objects"].append({"origin": [1.0, 2.0, 3.0], "r2": 4.0e8, "mtl": {"color": [0.3, 0.0, 0.3], "albedo": [1, 0, 0, 0, 0],
                                                                                "specular_exponent": 0, "refract_index": 1.0, "sampler": {"kind": 0}}})
+    elif variant == "coloured_flat_sky":
+        # flat (no light, no children) and constant in colour: its intersection test is skipped and waves that see only sky
+        # store the host-evaluated ambient term max(color*albedo[0], min(1, color*0 + color*0))
+        sky["mtl"].update(color=[0.2, 0.3, 0.9], albedo=[0.7, 0.0, 0.0, 0.0, 0.0])
+    elif variant == "textured_sky":
+        sky["mtl"].update(albedo=[1.0, 0.0, 0.0, 0.0, 0.0], sampler={"kind": 1, "texture": 0})     # flat but its colour needs the hit point: tested as before
+    elif variant == "negative_flat_sky":
+        sky["mtl"].update(color=[-0.5, 2.0, 0.25], albedo=[1.5, 0.0, 0.0, 0.0, 0.0])                  # the clamps of main.js:333-335 on odd values
     elif variant == "sky_not_last":
         s["objects"] = [sky] + [o for o in s["objects"] if o is not sky]  # tie-break order must not matter
     blob = rt_host.flatten_scene(s)
     w, h = 160, 90
     assert ou.max_lsb(gpu_frame(lib, blob, w, h), ou.c_oracle_render(blob, w, h))[0] <= 1
+    if variant in ("coloured_flat_sky", "negative_flat_sky"):            # and supersampled (the wave shortcut feeds the 2x2 box filter)
+        s["supersample"] = 2
+        blob = rt_host.flatten_scene(s)
+        assert ou.max_lsb(gpu_frame(lib, blob, 96, 50), ou.c_oracle_render(blob, 96, 50))[0] <= 1
 
 
 def test_batch_launch_equals_per_frame_launches(lib):
@@ -983,3 +1000,50 @@ def test_supersample_3x3_and_4x4_tiles_scatter_and_pieces(lib, k, flags):
         got = np.frombuffer(gpu_frame(lib, blob, w, h), dtype=np.uint8).reshape(h, w * 4)[rows]
         want = np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8).reshape(len(rows), w * 4)
         assert ou.max_lsb(np.ascontiguousarray(got), want)[0] <= 1, k
+
+
+def test_the_one_intrinsic_exception_ocml_vs_libm(lib):
+    """Seed 110793 of round 1's 30 000-scene soak: ONE pixel - a depth-5 refraction tree between two large spheres - where
+    BOTH kernels give the same colour, 4 LSB away from the C and JS restatements (which agree with each other and with the
+    reference): OCML's atan2 / asin / pow differ from glibc's and V8's in the last ulp (as those two differ from each other
+    on 6-18 % of their inputs) and here that ulp lands on a discontinuity.  Intrinsic to running on another
+    maths library; pinned so that it stays ONE pixel and both kernels keep agreeing."""
+    scene, w, h = _soak_scene(110793)
+    blob = rt_host.flatten_scene(scene)
+    want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
+    a = np.frombuffer(gpu_frame(lib, blob, w, h, FAST), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
+    b = np.frombuffer(gpu_frame(lib, blob, w, h, STRICT), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
+    assert np.abs(a - b).max() <= 1
+    for got in (a, b):
+        off = np.abs(got - want).max(axis=2) > 1
+        assert off.sum() <= 1 and np.abs(got - want).max() <= 4, (int(off.sum()), int(np.abs(got - want).max()))
+
+
+def test_launch_table_cache_and_per_call_tables(lib):
+    """The product kernel's launch table is cached per (frame size, tile set), at most 64 per scene; a scene rendered with more
+    than that gets per-call tables.  Same scene, 70 frame sizes and a few tile sets through ONE resident scene: every frame
+    must be the restatement's, and a cached size rendered again must give the same bytes."""
+    blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
+    r = rt_host.Renderer(blob, 0, lib)
+    d = lib.rt_alloc_device(0, 128 * 64 * 4)
+    host = C.create_string_buffer(128 * 64 * 4)
+    first = None
+    try:
+        for i in range(70):
+            w, h = 24 + i, 9 + (i % 5)
+            r.render_tiles(w, h, d, rt_host.RtTiles(h, 0, 1, 1), want_stats=True)
+            assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
+            got = host.raw[:w * h * 4]
+            if i == 0:
+                first = got
+            if i in (0, 31, 63, 64, 69):
+                assert ou.max_lsb(got, ou.c_oracle_render(blob, w, h))[0] <= 1, i
+        r.render_tiles(24, 9, d, rt_host.RtTiles(9, 0, 1, 1), want_stats=True)           # a cached one again
+        assert lib.rt_copy_to_host(0, host, d, 24 * 9 * 4) == 0
+        assert host.raw[:24 * 9 * 4] == first
+        r.render_tiles(93, 13, d, rt_host.RtTiles(8, 1, 2, 1), want_stats=True)           # a per-call one with another tile set: rows 8..12
+        assert lib.rt_copy_to_host(0, host, d, 93 * 5 * 4) == 0
+        assert ou.max_lsb(host.raw[:93 * 5 * 4], ou.c_oracle_render(blob, 93, 13, 8, 13))[0] <= 1
+    finally:
+        r.close()
+        lib.rt_free_device(0, d)
