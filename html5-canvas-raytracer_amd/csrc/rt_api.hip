@@ -914,6 +914,15 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     K.enclosing_flat = (order_b && s->enclosing_flat) ? 1u : 0u;
     K.sky_fast = (K.enclosing_flat && s->sky_const) ? 1u : 0u;
     for (int c = 0; c < 3; c++) K.sky_rgb[c] = s->sky_rgb[c];
+    memcpy(K.miss_color, hd.miss_color, sizeof K.miss_color);
+    if (K.sky_fast) {
+      // A flat sky of constant colour needs no hit record at all: "met nothing in the loops" IS "met the sky", whose pixel term
+      // is the constant the host evaluated - so for the product kernel that constant takes the place of the miss colour
+      // (main.js:231 is unreachable in such a scene: the sky encloses every ray) and the sphere leaves the kernel's view.
+      // Lanes that end on the sky then take the two-instruction miss branch, at every level of the ray tree.
+      K.enclosing = ~0u;
+      memcpy(K.miss_color, s->sky_rgb, sizeof K.miss_color);
+    }
   };
   auto lds_for = [&](bool strict) {
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
@@ -930,7 +939,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   const double projA = hd.fov_deg * M_PI / 180.0;
   L.proj_w = sw / 2.0; L.proj_h = sh / 2.0; L.proj_d = L.proj_w / tan(projA / 2.0);
   L.epsilon = hd.epsilon; L.light_intensity = hd.light_intensity;
-  memcpy(L.miss_color, hd.miss_color, sizeof L.miss_color);
   L.n_objects = hd.n_objects; L.n_lights = hd.n_lights; L.segs = hd.segs;
   L.w = w; L.h = h;
   L.tile_rows = tiles->tile_rows; L.tile_first = tiles->tile_first; L.tile_stride = tiles->tile_stride; L.n_tiles = tiles->n_tiles;

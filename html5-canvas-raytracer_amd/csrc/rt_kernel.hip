@@ -575,7 +575,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
 #if defined(RT_TESTING) && defined(RT_ABLATE_SHADE)
       if (true) { ret[0] = ht; ret[1] = (double)hcode; ret[2] = 0.0; } else
 #endif
-      if (hcode < 0) {                                // main.js:231
+      if (hcode < 0) {                                // main.js:231 (with a flat sky of constant colour: that sky's pixel term, see rt_api.hip bind_kernel)
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
 #ifdef RT_TESTING
         if (is_probe && probe_n < RT_PROBE_NODES) {
