@@ -686,8 +686,10 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
       return e.d_order;
   const uint32_t rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                                // output rows a workgroup covers
   const uint32_t wg_w = RT_TILE_W * ss, wg_h = rows_per_wg * ss;                        // ... and samples
-  // small launches have no tail worth ranking; the COUNT variant and the A/B switch keep the grid's order as well
-  const bool rank = ranked && n >= 4096u;
+  // small launches have no tail worth ranking, and for very large ones (cfg5 on one GPU: 4.2 M workgroups, an 18 ms kernel) the
+  // tail is noise while the ranking itself would cost the host a few hundred ms; the COUNT variant and the A/B switch keep the
+  // grid's order as well
+  const bool rank = ranked && n >= 4096u && n <= (1u << 20);
   std::vector<uint32_t> cost;
   uint32_t cmax = 1;
   if (rank) {

@@ -1047,3 +1047,22 @@ def test_launch_table_cache_and_per_call_tables(lib):
     finally:
         r.close()
         lib.rt_free_device(0, d)
+
+
+def test_rt_init_does_not_silently_change_the_device_count(lib):
+    """A second rt_init asking for a different number of GPUs is RT_ERR_STATE (-5), not a silent change of how rt_render
+    shards a frame; 0 ("whatever is in use") and the same number are fine.  Four emulated devices, test build, own process."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import rt_host; lib = rt_host.load_library();"
+            "print('RC', lib.rt_init(2), lib.rt_device_count(), lib.rt_init(3), lib.rt_init(0), lib.rt_init(2), lib.rt_init(1), lib.rt_device_count());"
+            "print('ERR', lib.rt_last_error().decode()); lib.rt_shutdown(); print('RC2', lib.rt_init(3), lib.rt_device_count())"
+            % os.path.join(ou.ROOT, "html5-canvas-raytracer_amd"))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, RT_HIP_LIB=rt_host.TEST_LIB_PATH, RT_EMULATE_DEVICES="4"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines() if l.split() and l.split()[0] in ("RC", "RC2")}
+    assert out["RC"] == ["0", "2", "-5", "0", "0", "-5", "2"], r.stdout
+    assert "already initialised with 2 device(s)" in r.stdout
+    assert out["RC2"] == ["0", "3"]
