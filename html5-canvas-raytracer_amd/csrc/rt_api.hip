@@ -426,6 +426,22 @@ extern "C" int rt_scene_cull_rects(const void *blob, size_t bytes, double *out) 
   return RT_OK;
 }
 
+// ------------------------------------------------------------------------------------ tile cost weights (host logic)
+namespace {
+void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vector<rt_geom> *cull, std::vector<uint32_t> *weight) {
+  cull->resize(hd->n_objects);
+  weight->resize(hd->n_objects);
+  for (uint32_t i = 0; i < hd->n_objects; i++) {
+    (*cull)[i] = cull_rect(hd, ob[i]);
+    const bool lit = ob[i].albedo[1] > 0.0 || ob[i].albedo[2] > 0.0, refl = ob[i].albedo[3] > 0.0, refr = ob[i].albedo[4] > 0.0;
+    const uint32_t depth = hd->segs > 1 ? (hd->segs - 1 < 4 ? hd->segs - 1 : 4) : 0;
+    uint32_t wgt = (lit ? 2u : 0u) + ((refl || refr) ? 3u * depth : 0u);
+    if (refl && refr && hd->segs > 1) wgt += 8u * (1u << (hd->segs - 1 < 5 ? hd->segs - 1 : 5));
+    (*weight)[i] = wgt;
+  }
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------ upload
 extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
   if (!out) return fail(RT_ERR_INVALID, "out handle is NULL");
@@ -496,16 +512,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   // cost-ordered dispatch: what a tile that shows sphere j is expected to cost, in rough units of one shaded hit - a guess
   // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
   // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
-  s->host_cull.resize(hd->n_objects);
-  s->tile_weight.resize(hd->n_objects);
-  for (uint32_t i = 0; i < hd->n_objects; i++) {
-    s->host_cull[i] = cull_rect(hd, ob[i]);
-    const bool lit = ob[i].albedo[1] > 0.0 || ob[i].albedo[2] > 0.0, refl = ob[i].albedo[3] > 0.0, refr = ob[i].albedo[4] > 0.0;
-    const uint32_t depth = hd->segs > 1 ? (hd->segs - 1 < 4 ? hd->segs - 1 : 4) : 0;
-    uint32_t wgt = (lit ? 2u : 0u) + ((refl || refr) ? 3u * depth : 0u);
-    if (refl && refr && hd->segs > 1) wgt += 8u * (1u << (hd->segs - 1 < 5 ? hd->segs - 1 : 5));
-    s->tile_weight[i] = wgt;
-  }
+  scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
   // device copy of the blob: the `reserved` slot of each sphere record carries 1/r for the product kernel
   std::vector<uint8_t> patched((const uint8_t *)blob, (const uint8_t *)blob + bytes);
   {
@@ -672,18 +679,14 @@ namespace {
 // cost estimate (the weights of the spheres whose screen rectangle - the primary-ray cull's - touches the tile) and lists
 // them dearest first, so the launch ends on sky.  Every tile is still rendered exactly once by exactly one workgroup: the
 // picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
-const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked, bool *temporary) {
-  *temporary = false;
+// (pure host logic: `cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns 2 words per entry, 8 * ceil(n/8)
+// entries; empty on a launch that is too large for the table)
+std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight, uint32_t w, uint32_t h, uint32_t ss,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
-  if (tiles_x > 2048u || n64 >= (1ull << 31)) { fail(RT_ERR_INVALID, "launch of %llu workgroups is beyond the launch table", (unsigned long long)n64); return nullptr; }
+  if (tiles_x > 2048u || n64 >= (1ull << 31) || n64 == 0) { fail(RT_ERR_INVALID, "launch of %llu workgroups is beyond the launch table", (unsigned long long)n64); return {}; }
   const uint32_t n = (uint32_t)n64;
-  std::lock_guard<std::mutex> lk(s->order_mu);
-  for (const rt_scene_dev::order_entry &e : s->orders)
-    if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
-        e.n_tiles == tiles->n_tiles && e.ranked == ranked)
-      return e.d_order;
   const uint32_t rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                                // output rows a workgroup covers
   const uint32_t wg_w = RT_TILE_W * ss, wg_h = rows_per_wg * ss;                        // ... and samples
   // small launches have no tail worth ranking, and for very large ones (cfg5 on one GPU: 4.2 M workgroups, an 18 ms kernel) the
@@ -696,10 +699,10 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
     // per-tile cost: every sphere's rectangle, in sample coordinates, rasterised onto the workgroup grid
     cost.assign(n, 1u);
     const double W = (double)w * ss, H = (double)h * ss;
-    for (size_t j = 0; j < s->host_cull.size(); j++) {
-      const uint32_t wgt = s->tile_weight[j];
+    for (size_t j = 0; j < cull.size(); j++) {
+      const uint32_t wgt = weight[j];
       if (!wgt) continue;
-      const rt_geom &r = s->host_cull[j];                    // {x_lo, x_hi, y_lo, y_hi} in units of 1/D; X = sx - W/2 + 0.5, Y = H/2 - sy - 0.5
+      const rt_geom &r = cull[j];                    // {x_lo, x_hi, y_lo, y_hi} in units of 1/D; X = sx - W/2 + 0.5, Y = H/2 - sy - 0.5
       const double sx0 = r.ox * proj_d + proj_w - 0.5, sx1 = r.oy * proj_d + proj_w - 0.5;
       const double sy0 = proj_h - 0.5 - r.r2 * proj_d, sy1 = proj_h - 0.5 - r.oz * proj_d;        // y grows downwards
       if (!(sx1 >= 0.0) || !(sx0 <= W) || !(sy1 >= 0.0) || !(sy0 <= H)) continue;            // off screen
@@ -741,6 +744,19 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
       table[2u * at] = w0 | x; table[2u * at + 1u] = w1;
     }
   }
+  return table;
+}
+
+const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
+                           double proj_w, double proj_h, double proj_d, bool ranked, bool *temporary) {
+  *temporary = false;
+  std::lock_guard<std::mutex> lk(s->order_mu);
+  for (const rt_scene_dev::order_entry &e : s->orders)
+    if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked)
+      return e.d_order;
+  const std::vector<uint32_t> table = build_launch_table(s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, ranked);
+  if (table.empty()) return nullptr;
   uint32_t *d = nullptr;
   hipError_t e = hipMalloc((void **)&d, table.size() * 4u);
   if (e == hipSuccess) e = hipMemcpy(d, table.data(), table.size() * 4u, hipMemcpyHostToDevice);
@@ -753,6 +769,35 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
   return d;
 }
 
+}  // namespace
+
+// Host-logic probe (no GPU): the product kernel's launch table for `tiles` of the w x h frame, exactly as render_batch_impl
+// builds it: out_entries receives 2 words per entry, 8 * ceil(n / 8) entries with workgroup b's entry at (b % 8) * ceil(n / 8)
+// + b / 8; *n_workgroups = n.  Pass out_entries = NULL to ask for n only.
+extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
+                                     uint32_t *out_entries, uint32_t *n_workgroups) {
+  int rc = rt_scene_validate(blob, bytes);
+  if (rc) return rc;
+  if (!tiles || !n_workgroups || w == 0 || h == 0 || w > 65536 || h > 65536 || tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0)
+    return fail(RT_ERR_INVALID, "bad launch-table probe arguments");
+  const rt_scene_header *hd = (const rt_scene_header *)blob;
+  if (hd->supersample > 2) return fail(RT_ERR_INVALID, "supersample 3 and 4 launch on the sample grid: probe that size with a supersample-1 scene");
+  const rt_sphere *ob = (const rt_sphere *)((const uint8_t *)blob + hd->objects_offset);
+  std::vector<rt_geom> cull;
+  std::vector<uint32_t> weight;
+  scene_tile_weights(hd, ob, &cull, &weight);
+  const uint32_t ss = hd->supersample, rows_per_wg = ss == 2u ? 2u : RT_TILE_H;
+  const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
+  if ((uint64_t)tiles->n_tiles * rb_per_tile > 65535u) return fail(RT_ERR_INVALID, "too many row blocks");
+  const double pw = (double)w * ss / 2.0, ph = (double)h * ss / 2.0, pd = pw / tan(hd->fov_deg * M_PI / 180.0 / 2.0);
+  const std::vector<uint32_t> table = build_launch_table(cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, ranked != 0);
+  if (table.empty()) return RT_ERR_INVALID;
+  *n_workgroups = tiles_x * tiles->n_tiles * rb_per_tile;
+  if (out_entries) memcpy(out_entries, table.data(), table.size() * sizeof(uint32_t));
+  return RT_OK;
+}
+
+namespace {
 // k x k box filter of the two-pass supersampling (k = 3, 4): `src` holds the rendered SAMPLES of this call's tiles as a band
 // (rows of k*w RGBA8 samples, k sample rows per output row, tiles contiguous), the output pixel is (sum + k*k/2) / (k*k) per
 // channel, alpha 255, stored where the trace kernel would have stored it: in the band (`out`, frame f at f*frame_stride) or,

@@ -148,6 +148,8 @@ ABI = {
     "rt_scene_validate": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_scene_cull_rects": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
     "rt_scene_bounce_candidates": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rt_scene_launch_table": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_int, C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32)]),
     "rt_scene_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_scene_free": (None, [C.c_void_p]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_void_p, C.c_void_p,

@@ -167,6 +167,15 @@ int rt_scene_cull_rects(const void *scene_blob, size_t blob_bytes, double *out_4
  * set if sphere j is tested.  Conservative by construction: every sphere such a ray can meet is in the set. */
 int rt_scene_bounce_candidates(const void *scene_blob, size_t blob_bytes, uint32_t from, const double dir[3], uint64_t *out_words);
 
+/* Host-logic probe (no GPU): the launch table of the product kernel for `tiles` of the w x h frame (scene supersample 1 or 2).
+ * The kernel runs on a flat grid; workgroup b renders the 32-pixel-wide, 8-row (2 with supersample 2) block described by its
+ * 8-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in this call's output band}, stored at index
+ * (b % 8) * ceil(n / 8) + b / 8.  With `ranked` the blocks are listed dearest first (a cost estimate from the spheres' screen
+ * rectangles), which is the order the hardware then hands them out in.  out_entries: 16 * ceil(n / 8) words, or NULL to ask
+ * for *n_workgroups only. */
+int rt_scene_launch_table(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
+                          uint32_t *out_entries, uint32_t *n_workgroups);
+
 /* Upload a scene to `device` (index into the GPUs in use) and keep it resident. */
 int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_scene_dev **out);
 void rt_scene_free(rt_scene_dev *scene);

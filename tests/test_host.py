@@ -292,3 +292,98 @@ def test_build_stamp_and_elapsed_report(built):
     small = C.create_string_buffer(8)
     st.total_ms = 7.0
     assert lib.rt_elapsed_report(C.byref(st), small, 8) == len("build #%s (7ms)" % rt_host.build_id(lib)) and small.value == b"build #"    # snprintf rule
+
+
+def _launch_table(lib, blob, w, h, tiles, ranked):
+    import ctypes as C
+    buf = C.create_string_buffer(blob, len(blob))
+    t = rt_host.RtTiles(*tiles)
+    n = C.c_uint32()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), None, C.byref(n)) == 0, lib.rt_last_error()
+    n8 = (n.value + 7) // 8
+    out = (C.c_uint32 * (16 * n8))()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), out, C.byref(n)) == 0
+    entries = []
+    for b in range(n.value):
+        at = (b % 8) * n8 + b // 8                           # one contiguous part of the table per XCD
+        e0, e1 = out[2 * at], out[2 * at + 1]
+        entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1))      # tile_x, rows_valid, first frame row, first band row
+    return entries
+
+
+@pytest.mark.parametrize("scene,w,h,tiles", [
+    ("h8", 3840, 2160, (2160, 0, 1, 1)),          # the headline launch: 32 400 workgroups, ranked
+    ("h8", 3840, 2160, (16, 3, 8, 17)),           # rank 3 of 8: interleaved 16-row tiles, the last one past the frame's end
+    ("default14", 203, 97, (97, 0, 1, 1)),        # ragged, below the ranking threshold
+    ("lcg64", 4096, 1031, (24, 1, 2, 22)),        # supersample 2: 2 rows per workgroup, general tile split
+    ("cfg1", 1, 1, (1, 0, 1, 1))])
+def test_launch_table_lists_every_block_exactly_once(built, scene, w, h, tiles):
+    """Host logic of the product kernel's launch table (csrc/rt_api.hip build_launch_table, through the rt_scene_launch_table
+    probe): whatever the order, the entries are exactly the blocks of the tile set - every (tile column, first frame row) once,
+    with the band row the plain grid would have used and the number of rows inside the tile and the frame - and the ranked table
+    is a permutation of the unranked one that never lists a dearer block after a cheaper one."""
+    import math
+    lib = rt_host.load_library()
+    sc = rt_host.load_scene(scene)
+    blob = rt_host.flatten_scene(sc)
+    ss = sc.get("supersample", 1)
+    rows_per_wg = 2 if ss == 2 else 8
+    tile_rows, first, stride, n_tiles = tiles
+    tiles_x = (w + 31) // 32
+    rb = (tile_rows + rows_per_wg - 1) // rows_per_wg
+    expect = []
+    for i in range(n_tiles):
+        for r in range(rb):
+            trow0 = r * rows_per_wg
+            frow0 = (first + i * stride) * tile_rows + trow0
+            valid = max(0, min(rows_per_wg, tile_rows - trow0, h - frow0)) if frow0 < h else 0
+            for x in range(tiles_x):
+                expect.append((x, valid, frow0 if frow0 < h else 0, i * tile_rows + trow0))
+    plain = _launch_table(lib, blob, w, h, tiles, False)
+    assert plain == expect                                   # unranked = the plain grid's own order
+    ranked = _launch_table(lib, blob, w, h, tiles, True)
+    assert sorted(ranked) == sorted(expect)
+    if len(expect) < 4096:
+        assert ranked == expect                              # small launches are not ranked
+        return
+    # cost of a block, restated from the screen rectangles (rt_scene_cull_rects) and the weights of build_launch_table
+    import ctypes as C
+    rects = (C.c_double * (4 * len(sc["objects"])))()
+    buf = C.create_string_buffer(blob, len(blob))
+    assert lib.rt_scene_cull_rects(buf, len(blob), rects) == 0
+    segs = sc["segs"]
+    W, H = w * ss, h * ss
+    pw, ph = W / 2.0, H / 2.0
+    pd = pw / math.tan(sc.get("fovDeg", 60) * math.pi / 180 / 2)
+    wg_w, wg_h = 32 * ss, rows_per_wg * ss
+
+    def weight(o):
+        a = o["mtl"]["albedo"]
+        depth = min(segs - 1, 4) if segs > 1 else 0
+        wgt = (2 if (a[1] > 0 or a[2] > 0) else 0) + (3 * depth if (a[3] > 0 or a[4] > 0) else 0)
+        if a[3] > 0 and a[4] > 0 and segs > 1:
+            wgt += 8 * (1 << min(segs - 1, 5))
+        return wgt
+
+    def cost(x, frow0):
+        c = 1
+        row0 = frow0 * ss
+        for j, o in enumerate(sc["objects"]):
+            wgt = weight(o)
+            if not wgt:
+                continue
+            x_lo, x_hi, y_lo, y_hi = rects[4 * j:4 * j + 4]
+            sx0, sx1 = x_lo * pd + pw - 0.5, x_hi * pd + pw - 0.5
+            sy0, sy1 = ph - 0.5 - y_hi * pd, ph - 0.5 - y_lo * pd
+            if not (sx1 >= 0) or not (sx0 <= W) or not (sy1 >= 0) or not (sy0 <= H):
+                continue
+            tx0, tx1 = int(max(sx0, 0.0) / wg_w), int(min(min(sx1, W - 1.0) / wg_w, tiles_x - 1))
+            ys0, ys1 = max(sy0, 0.0), min(sy1, H - 1.0)
+            if row0 + wg_h <= ys0 or row0 > ys1 or not (tx0 <= x <= tx1):
+                continue
+            c += wgt
+        return c
+
+    costs = [cost(x, fr) for x, _, fr, _ in ranked]
+    assert all(a >= b for a, b in zip(costs, costs[1:]))     # dearest first
+    assert costs[0] > costs[-1]                              # ... and the frame does end on cheaper blocks (sky) than it starts with
