@@ -549,6 +549,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   }
   hipError_t e = hipMalloc(&s->d_blob, bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
+  geom.push_back(rt_geom{0.0, 0.0, 0.0, -1.0});        // one record of padding: the kernel's scans fetch a light's first two records at once, also when it has one
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
   if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
   {

@@ -173,63 +173,73 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
 // sensitivity at boundaries that OCML, glibc and V8 already have among themselves (the one listed
 // exception); the parity suite and the soaks hold the result to 1 LSB.
 #if RT_STRICT || (defined(RT_TESTING) && defined(RT_AB_OCML_TRIG))
-__device__ __forceinline__ double rt_atan2(double y, double x) { return atan2(y, x); }
-__device__ __forceinline__ double rt_asin(double x) { return asin(x); }
+// atan2(y, x) and asin(w) of one surface normal (the two halves of main.js:446-447 / :127-128)
+__device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) { *at = atan2(y, x); *as = asin(w); }
 #else
 __device__ __forceinline__ double rt_fma_k(double a, double b, double k) {     // a*b + k, k wave-uniform: v_fma_f64 v, v, v, s[..]
   double r;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
   return r;
 }
-// the polynomial coefficients (OCML's, as 64-bit patterns): a table in constant memory, read with scalar loads - an s_load_dwordx16
-// brings eight of them into SGPRs with ONE scalar instruction, where immediates would take two s_mov_b32 each (the scalar unit
-// is shared by the CU's four SIMDs and is ~60 % busy in this kernel: measured, immediates made the kernel slower)
-__constant__ unsigned long long RT_TRIG_BITS[32] = {
-    // atan: c0 .. c19, highest degree first
-    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull, 0x3f7d6d43a595c56full, 0xbf8c6ea4a57d9582ull,
-    0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull, 0x3fa2c15b5711927aull, 0xbfa59976e82d3ff0ull, 0x3fa82d5d6ef28734ull, 0xbfaae5ce6a214619ull,
-    0x3fae1bb48427b883ull, 0xbfb110e48b207f05ull, 0x3fb3b13657b87036ull, 0xbfb745d119378e4full, 0x3fbc71c717e1913cull, 0xbfc2492492376b7dull,
-    0x3fc99999999952ccull, 0xbfd5555555555523ull,
-    // asin: c0 .. c11
-    0x3fa059859fea6a70ull, 0xbf90a5a378a05eafull, 0x3f94052137024d6aull, 0x3f7ab3a098a70509ull, 0x3f88ed60a300c8d2ull, 0x3f8c6fa84b77012bull,
-    0x3f91c6c111dccb70ull, 0x3f96e89f0a0adacfull, 0x3f9f1c72c668963full, 0x3fa6db6db41ce4bdull, 0x3fb333333336fd5bull, 0x3fc5555555555380ull};
 typedef const double __attribute__((address_space(4))) *rt_trig_kptr;
-__device__ __forceinline__ rt_trig_kptr rt_trig_table() {
-  rt_trig_kptr t = (rt_trig_kptr)(const void *)RT_TRIG_BITS;
-  asm volatile("" : "+s"(t));                        // opaque: the reads below stay scalar LOADS instead of being folded back into immediates
-  return t;
-}
-__device__ __forceinline__ double rt_atan2(double y, double x) {
+typedef double __attribute__((ext_vector_type(8))) rt_d8;
+// The polynomial coefficients (OCML's, as 64-bit patterns) sit in a constant-memory table read with scalar loads: an
+// s_load_dwordx16 brings eight of them into SGPRs with ONE scalar instruction, where immediates would take two s_mov_b32 each
+// (the scalar unit is shared by the CU's four SIMDs and is ~60 % busy in this kernel: measured, immediates made the kernel slower).
+// The two Horner chains are independent, so their steps ALTERNATE (a dependent v_fma_f64 waits for its predecessor; the other
+// chain's step fills the gap), and the coefficients come in four 64-byte groups laid out for that order - atan c0..7 | atan
+// c8..11, asin c0..3 | atan c12..15, asin c4..7 | atan c16..19, asin c8..11 - each fetched by ONE s_load_dwordx16 a segment
+// ahead of its use, the first before the quotient's dependent chain.
+__constant__ unsigned long long RT_TRIG_BITS[32] = {
+    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull, 0x3f7d6d43a595c56full, 0xbf8c6ea4a57d9582ull,
+    0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull,
+    0x3fa2c15b5711927aull, 0xbfa59976e82d3ff0ull, 0x3fa82d5d6ef28734ull, 0xbfaae5ce6a214619ull,
+    0x3fa059859fea6a70ull, 0xbf90a5a378a05eafull, 0x3f94052137024d6aull, 0x3f7ab3a098a70509ull,
+    0x3fae1bb48427b883ull, 0xbfb110e48b207f05ull, 0x3fb3b13657b87036ull, 0xbfb745d119378e4full,
+    0x3f88ed60a300c8d2ull, 0x3f8c6fa84b77012bull, 0x3f91c6c111dccb70ull, 0x3f96e89f0a0adacfull,
+    0x3fbc71c717e1913cull, 0xbfc2492492376b7dull, 0x3fc99999999952ccull, 0xbfd5555555555523ull,
+    0x3f9f1c72c668963full, 0x3fa6db6db41ce4bdull, 0x3fb333333336fd5bull, 0x3fc5555555555380ull};
+__device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) {
+  rt_trig_kptr K = (rt_trig_kptr)(const void *)RT_TRIG_BITS;
+  asm volatile("" : "+s"(K));                        // opaque: the reads below stay scalar LOADS instead of being folded back into immediates
+  const rt_d8 k0 = *(const rt_d8 __attribute__((address_space(4))) *)K;
   const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
   const double hi = __builtin_fmax(ax, ay), lo = __builtin_fmin(ax, ay);
   const double q = rt_div(lo, hi);                                   // in [0,1]; 0/0 (both zero) handled below
   const double z = q * q;
-  const rt_trig_kptr K = rt_trig_table();
-  double p = K[0];
+  const double yw = __builtin_fabs(w);
+  const double t = __builtin_fma(yw, -0.5, 0.5);                     // (1 - |w|) / 2
+  const bool big = (yw >= 0.5);
+  const double r = big ? t : w * w;
+  const rt_d8 k1 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 8);
+  double p = k0[0];
 #pragma unroll
-  for (uint32_t i = 1; i < 20; i++) p = rt_fma_k(p, z, K[i]);
+  for (uint32_t i = 1; i < 8; i++) p = rt_fma_k(p, z, k0[i]);
+  const rt_d8 k2 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 16);
+  double pa = k1[4];
+  p = rt_fma_k(p, z, k1[0]); pa = rt_fma_k(pa, r, k1[5]);
+  p = rt_fma_k(p, z, k1[1]); pa = rt_fma_k(pa, r, k1[6]);
+  p = rt_fma_k(p, z, k1[2]); pa = rt_fma_k(pa, r, k1[7]);
+  p = rt_fma_k(p, z, k1[3]);
+  const rt_d8 k3 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 24);
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) { p = rt_fma_k(p, z, k2[i]); pa = rt_fma_k(pa, r, k2[4 + i]); }
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) { p = rt_fma_k(p, z, k3[i]); pa = rt_fma_k(pa, r, k3[4 + i]); }
+  // atan2: quadrant and special cases
   double a = __builtin_fma(q, z * p, q);                             // atan(q), q in [0,1]
   a = (ay > ax) ? (M_PI / 2.0 - a) : a;
   const bool xneg = (__builtin_bit_cast(unsigned long long, x) >> 63) != 0;      // the sign BIT: atan2(+-0, -0) = +-pi
   a = xneg ? (M_PI - a) : a;
   a = (hi == 0.0) ? (xneg ? M_PI : 0.0) : a;                         // atan2(+-0, +-0)
-  return __builtin_copysign(a, y);                                   // NaN in, NaN out (every step above propagates it)
-}
-__device__ __forceinline__ double rt_asin(double x) {
-  const double y = __builtin_fabs(x);
-  const double t = __builtin_fma(y, -0.5, 0.5);                      // (1 - |x|) / 2
-  const bool big = (y >= 0.5);
-  const double r = big ? t : x * x;
-  const rt_trig_kptr K = rt_trig_table();
-  double p = K[20];
-#pragma unroll
-  for (uint32_t i = 21; i < 32; i++) p = rt_fma_k(p, r, K[i]);
-  p = p * r;
-  const double s = big ? rt_sqrt_nn(t) : y;
-  const double w = __builtin_fma(s, p, s);                           // asin(s)
-  double a = big ? __builtin_fma(-2.0, w, M_PI / 2.0) : w;
-  a = (y > 1.0) ? __builtin_nan("") : a;                             // |x| > 1 by an ulp (a ray through the exact pole): NaN, as Math.asin gives
-  return __builtin_copysign(a, x);
+  *at = __builtin_copysign(a, y);                                    // NaN in, NaN out (every step above propagates it)
+  // asin: x + x*r*P(r) below 1/2, pi/2 - 2*asin(sqrt((1-|x|)/2)) above
+  pa = pa * r;
+  const double sq = big ? rt_sqrt_nn(t) : yw;
+  const double ww = __builtin_fma(sq, pa, sq);                       // asin(sq)
+  double b = big ? __builtin_fma(-2.0, ww, M_PI / 2.0) : ww;
+  b = (yw > 1.0) ? __builtin_nan("") : b;                            // |w| > 1 by an ulp (a ray through the exact pole): NaN, as Math.asin gives
+  *as = __builtin_copysign(b, w);
 }
 #endif
 
@@ -379,6 +389,14 @@ __device__ __forceinline__ rt_geom rt_load_geom32(geom_kptr tab, uint32_t i) {
   return rt_geom{g->ox, g->oy, g->oz, g->r2};
 }
 
+// two consecutive table records with ONE scalar load (s_load_dwordx16): one memory latency per two sphere tests
+struct rt_geom_pair { rt_geom a, b; };
+__device__ __forceinline__ rt_geom_pair rt_load_geom_pair32(geom_kptr tab, uint32_t i) {
+  typedef double __attribute__((ext_vector_type(8))) d8;
+  const d8 v = *(const d8 __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)tab + (i << 5));
+  return rt_geom_pair{rt_geom{v[0], v[1], v[2], v[3]}, rt_geom{v[4], v[5], v[6], v[7]}};
+}
+
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
@@ -450,7 +468,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
       // a 64-bit address computation per load (+0.8 % on the headline)
 #define RT_LOAD(TAB, I) rt_load_geom32((TAB), (uint32_t)(I))
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
-      // the compiler's runtime unrolling); the two s_load_dwordx8 of a pair are issued together.
+      // the compiler's runtime unrolling); a pair's two records come with ONE s_load_dwordx16 (rt_load_geom_pair32).
   if (segs_left != 0) {
         // Primary rays.  First a wave-wide cull: lane j compares sphere j's conservative screen rectangle
         // (host, resolution-independent: bounds of X/D and Y/D over the pixels whose LINE meets the sphere)
@@ -544,7 +562,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           ht = RT_INF; hcode = -1;
           uint32_t i = 0;
           for (; i + 2 <= NLOOP; i += 2) {
-            const rt_geom g0 = RT_LOAD(geom, i), g1 = RT_LOAD(geom, i + 1);
+            const rt_geom_pair gp = rt_load_geom_pair32(geom, i);
+            const rt_geom g0 = gp.a, g1 = gp.b;
             RT_GENERIC(i, g0) RT_GENERIC(i + 1, g1)
           }
           if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
@@ -610,8 +629,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const int kind = m.sampler_kind;
 #endif
         if (kind == RT_SAMPLER_TEXTURE) {
-          const double u = RT_DIV_CONST(rt_atan2(-n.z, -n.x), M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
-          const double v = RT_DIV_CONST(rt_asin(-n.y), M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
+          double t_at, t_as;
+          rt_atan2_asin(-n.z, -n.x, -n.y, &t_at, &t_as);
+          const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
+          const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
           const rt_texture_desc td = tex[m.texture];
           const double xd = ceil(u * (double)td.width) - 1.0, yd = ceil(v * (double)td.height) - 1.0;
           uint32_t xi = (xd > 0.0) ? (uint32_t)xd : 0u, yi = (yd > 0.0) ? (uint32_t)yd : 0u;
@@ -621,8 +642,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
           if (xd != xd || yd != yd) col[0] = col[1] = col[2] = __builtin_nan("");   // texels[NaN] is undefined in JS
         } else if (kind == RT_SAMPLER_CHECKER) {
-          const double u = RT_DIV_CONST(rt_atan2(-n.y, -n.x), M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
-          const double v = RT_DIV_CONST(rt_asin(-n.z), M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
+          double t_at, t_as;
+          rt_atan2_asin(-n.y, -n.x, -n.z, &t_at, &t_as);
+          const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
+          const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
           col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
         } else if (kind == RT_SAMPLER_STARS) {
@@ -659,6 +682,13 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             double llen;
             // light k from the kernarg segment through a 32-bit byte offset (scalar load with an SGPR offset)
             const double *lk = (const double *)((const char *)&L.lights[0][0] + (uint32_t)(k * 24u));
+#if !RT_STRICT
+            // few spheres (no shadow grid): the scan's first two records are fetched HERE, with the light's position - their latency
+            // hides behind the light vector's normalisation instead of standing in front of the scan (a wave whose lanes all
+            // face away wasted one load); measured -0.3 % on the headline, and +0.4 % where the grid path made it a wasted load
+            [[maybe_unused]] rt_geom_pair gp_first;
+            if constexpr (!GRID && !COUNT) gp_first = rt_load_geom_pair32((geom_kptr)L.geom_light, k * L.n_objects);
+#endif
             const v3 sraw = mk(lk[0] - h.x, lk[1] - h.y, lk[2] - h.z);
             const double lmag = dot(sraw, sraw);
 #if RT_STRICT
@@ -779,8 +809,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
             if (!COUNT) {
               if (li != 0.0) {
                 uint32_t j = 0;
+#if !RT_STRICT
+                if constexpr (!GRID) {
+                  if (NS >= 2u) { const rt_geom g0 = gp_first.a, g1 = gp_first.b; RT_SHADOW_U(0u, g0) RT_SHADOW_U(1u, g1) j = 2u; }
+                }
+#endif
                 for (; j + 2 <= NS; j += 2) {
-                  const rt_geom g0 = RT_LOAD(gl, glo + j), g1 = RT_LOAD(gl, glo + j + 1);
+                  const rt_geom_pair gp = rt_load_geom_pair32(gl, glo + j);
+                  const rt_geom g0 = gp.a, g1 = gp.b;
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
                 if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }

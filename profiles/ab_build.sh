@@ -1,17 +1,18 @@
 #!/bin/bash
-# Build A/B variants of librt_hip.so with extra kernel flags:  profiles/ab_build.sh <name> "<KFLAGS>"
-# -> build/ab/librt_hip_<name>.so   (bench with RT_HIP_LIB=<that path>)
+# Build A/B variants of librt_hip.so with extra kernel flags:  profiles/ab_build.sh <name> "<KFLAGS>" [product]
+# -> build/ab/librt_hip_<name>.so   (bench with RT_HIP_LIB=<that path>); a test build (-DRT_TESTING) unless "product" is given
 set -e
-NAME=$1; FLAGS=$2
+NAME=$1; FLAGS=$2; TESTING=-DRT_TESTING; [ "${3:-}" = product ] && TESTING=
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$REPO/html5-canvas-raytracer_amd/csrc
 OUT=$REPO/build/ab; mkdir -p $OUT
 T=$(mktemp -d)
-COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -mllvm -disable-machine-licm -DRT_TESTING -I$SRC"
+COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -mllvm -disable-machine-licm $TESTING -I$SRC"
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=0 -ffp-contract=fast -c $SRC/rt_kernel.hip -o $T/kf.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=1 -ffp-contract=off -c $SRC/rt_kernel.hip -o $T/ks.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -c $SRC/rt_api.hip -o $T/api.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/librt_hip_$NAME.so $T/api.o $T/kf.o $T/ks.o -ldl
+cp $T/kf.o $OUT/rt_kernel_fast_$NAME.o      # for profiles/kernel_resources.sh / isa_histogram.sh
 rm -rf $T
 echo built $OUT/librt_hip_$NAME.so
