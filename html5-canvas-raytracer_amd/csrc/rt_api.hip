@@ -1,5 +1,6 @@
-// rt_api.hip — the C ABI of include/rt_hip.h: scene validation/upload, launches, pinned
-// framebuffers, and the single-process multi-GPU frame (interleaved row tiles + one RCCL gather).
+// rt_api.hip — the C ABI of include/rt_hip.h: scene validation/upload, the host-built tables (cull rectangles, shadow
+// grids, bounce table, launch table), launches, pinned framebuffers, and the single-process multi-GPU frame (interleaved
+// row tiles stored straight into GPU 0's frame over xGMI; fallback: RGB24 bands + one RCCL gather + de-interleave).
 //
 // Host-side counterpart of the reference's driver code: main() sets up what a frame needs
 // (main.js:77-105), redraw()/spanish() walks the rows (:180-201).  Here a frame is one kernel
@@ -1508,12 +1509,11 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
       if (!G.emulated && (rc = ensure_rccl(ndev))) return rc;      // nothing allocated yet
       // bands cross xGMI as RGB24 when the width allows it (the alpha byte is the constant 255, main.js:198; the
       // de-interleave restores it); tile_rows >= 8, so a band is a multiple of 96 bytes and d_final stays 16-byte aligned
-      const bool rgb24 = (w & 3u) == 0;
+      // (the 3x3 / 4x4 box filter of the two-pass supersampling stores RGBA8: those scenes gather RGBA8 bands)
+      for (int g = 0; g < ndev && !rc; g++) rc = scene_for(g, blob, bytes, &scenes[g]);
+      const bool rgb24 = (w & 3u) == 0 && !rc && scenes[0]->hd.supersample <= 2u;
       const size_t band_bytes = (size_t)tiles_per_rank * tile_rows * w * (rgb24 ? 3u : 4u);
-      for (int g = 0; g < ndev && !rc; g++) {
-        rc = scene_for(g, blob, bytes, &scenes[g]);
-        if (!rc) rc = ensure_frame(g, band_bytes);
-      }
+      for (int g = 0; g < ndev && !rc; g++) rc = ensure_frame(g, band_bytes);
       if (!rc && !(rc = ensure_device(0))) {
         device_state &R = G.dev[0];
         if (R.gather_bytes < band_bytes * ndev + frame_bytes) {

@@ -578,13 +578,14 @@ def test_rt_render_multi_device_plans(lib, devices, gather):
         ranks on one GPU); with devices == 1 it is the REAL RCCL path - ncclCommInitAll, ncclGroupStart/End and ncclGather
         on a one-rank communicator.
     Cases: 16-row tiles + RGB24 bands (headline size), 8-row tiles, a width that forces RGBA8 bands, odd sizes (centre row /
-    column fix-up launches inside the tiles), the general kernel, a frame too short to shard; every case twice with a
-    growing frame (the per-device buffers are re-allocated on the right device)."""
+    column fix-up launches inside the tiles), the general kernel, a frame too short to shard, cfg5's 2x2 supersampling and the
+    two-pass 3x3 one; every case twice with a growing frame (the per-device buffers are re-allocated on the right device)."""
     import hashlib
     import os
     import subprocess
     import sys
-    cases = [("h8", 3840, 1080), ("h8", 200, 150), ("h8", 203, 97), ("default14", 132, 80), ("cfg1", 64, 9)]
+    cases = [("h8", 3840, 1080), ("h8", 200, 150), ("h8", 203, 97), ("default14", 132, 80), ("cfg1", 64, 9),
+             ("lcg64", 128, 96), ("lcg64_ss3", 64, 72)]             # + 2x2 samples inside the kernel (cfg5), 3x3 two-pass (RGBA8 bands)
     env = dict(os.environ, RT_HIP_LIB=rt_host.TEST_LIB_PATH)          # the switches exist in the test build only
     if devices > 1:
         env["RT_EMULATE_DEVICES"] = str(devices)
