@@ -109,7 +109,8 @@ struct rt_scene_dev {
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
   uint64_t *d_shadow_grid;       // light grids for the product kernel's loop order, or NULL (few spheres)
   uint64_t *d_bounce_table;      // bounce table for the same order, or NULL (few spheres, or depth < 2)
-  uint8_t *d_lds_image;          // per ordering: [materials | 16 texture descriptors | cull rectangles], the LDS image
+  uint8_t *d_lds_image;          // per ordering: [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)], the LDS image
+  bool cull_in_lds;
   size_t lds_image_bytes;        // of one ordering
   rt_scene_header hd;            // host copy
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
@@ -474,7 +475,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
       if (fabs((x * x + y * y + z * z) - ob[i].r2) <= 1e-9 * fmax(ob[i].r2, 1.0)) s->needs_strict = true;
     }
   }
-  s->lds_bytes = hd->n_objects * (unsigned)(sizeof(rt_sphere) + sizeof(rt_geom)) + RT_MAX_TEXTURES * (unsigned)sizeof(rt_texture_desc);
+
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
   rt_texture_desc descs[RT_MAX_TEXTURES];
@@ -553,30 +554,52 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   geom.push_back(rt_geom{0.0, 0.0, 0.0, -1.0});        // one record of padding: the kernel's scans fetch a light's first two records at once, also when it has one
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
   if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
+  const uint32_t n_loop_b = has_b ? NO - 1 : NO;       // spheres in the product kernel's loops
+  static const uint32_t sgrid_min = RT_TEST_ENV("RT_SGRID_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;     // A/B switches (test build)
+  static const uint32_t btable_min = RT_TEST_ENV("RT_BTABLE_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;
+  const bool want_shadow_grid = n_loop_b > sgrid_min && hd->n_lights > 0;
+  const bool want_bounce_table = n_loop_b > btable_min && hd->segs > 1;      // rays bounce at all only from depth 2 on
   {
     // the LDS image, per ordering
-    s->lds_image_bytes = (size_t)NO * (sizeof(rt_sphere) + sizeof(rt_geom)) + sizeof descs;
+    // few spheres: the cull rectangles ride in the image as well; scenes that get a shadow grid or a bounce table (below) run the
+    // many-sphere kernel variant, which fetches them per lane (rt_kernel.hip: 64 spheres + the fold state then fit 32 KB of LDS,
+    // five workgroups per CU instead of four)
+    s->cull_in_lds = !(want_shadow_grid || want_bounce_table);
+    s->lds_image_bytes = (size_t)NO * (sizeof(rt_mtl) + (s->cull_in_lds ? sizeof(rt_geom) : 0u)) + sizeof descs;
+    s->lds_bytes = (unsigned)s->lds_image_bytes;
     std::vector<uint8_t> img(s->lds_image_bytes * (has_b ? 2 : 1));
     for (int ord = 0; ord < (has_b ? 2 : 1); ord++) {
       uint8_t *dst = img.data() + ord * s->lds_image_bytes;
-      memcpy(dst, ord ? (const void *)objs_b.data() : (const void *)pob_a, (size_t)NO * sizeof(rt_sphere));
-      memcpy(dst + (size_t)NO * sizeof(rt_sphere), descs, sizeof descs);
-      memcpy(dst + (size_t)NO * sizeof(rt_sphere) + sizeof descs, geom.data() + ord * per_order + 2 * (size_t)NO, (size_t)NO * sizeof(rt_geom));
+      const rt_sphere *src = ord ? objs_b.data() : pob_a;
+      rt_mtl *mt = (rt_mtl *)dst;
+      for (uint32_t i = 0; i < NO; i++) {
+        const rt_sphere &o = src[i];
+        rt_mtl &m = mt[i];
+        memset(&m, 0, sizeof m);
+        memcpy(m.origin, o.origin, sizeof m.origin);
+        m.inv_r = o.reserved;                           // 1/r, patched above
+        memcpy(m.albedo, o.albedo, sizeof m.albedo);
+        m.specular_exponent = o.specular_exponent; m.refract_index = o.refract_index;
+        m.sampler_kind = o.sampler_kind; m.texture = o.texture;
+        if (o.sampler_kind == RT_SAMPLER_CHECKER) memcpy(m.c, o.checker_color, 6 * sizeof(double));
+        else memcpy(m.c, o.color, 3 * sizeof(double));
+        m.c[6] = o.checker_freq[0]; m.c[7] = o.checker_freq[1];
+      }
+      memcpy(dst + (size_t)NO * sizeof(rt_mtl), descs, sizeof descs);
+      if (s->cull_in_lds) memcpy(dst + (size_t)NO * sizeof(rt_mtl) + sizeof descs, geom.data() + ord * per_order + 2 * (size_t)NO, (size_t)NO * sizeof(rt_geom));
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_lds_image, img.size());
     if (e == hipSuccess) e = hipMemcpy(s->d_lds_image, img.data(), img.size(), hipMemcpyHostToDevice);
   }
   {
     // shadow grids, in the loop order the product kernel uses (B when there is an enclosing sphere)
-    const uint32_t n_loop = has_b ? NO - 1 : NO;
-    static const uint32_t sgrid_min = RT_TEST_ENV("RT_SGRID_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;   // A/B switch
-    if (n_loop > sgrid_min && hd->n_lights > 0) {
+    const uint32_t n_loop = n_loop_b;
+    if (want_shadow_grid) {
       const std::vector<uint64_t> sg = build_shadow_grid(has_b ? objs_b.data() : pob_a, n_loop, hd->n_lights, s->lights);
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
       if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     }
-    static const uint32_t btable_min = RT_TEST_ENV("RT_BTABLE_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;   // A/B switch
-    if (n_loop > btable_min && hd->segs > 1) {      // rays bounce at all only from depth 2 on
+    if (want_bounce_table) {
       const std::vector<uint64_t> bt = build_bounce_table(has_b ? objs_b.data() : pob_a, NO, n_loop);
       if (e == hipSuccess) e = hipMalloc((void **)&s->d_bounce_table, bt.size() * sizeof(uint64_t));
       if (e == hipSuccess) e = hipMemcpy(s->d_bounce_table, bt.data(), bt.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
@@ -961,6 +984,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     K.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
     K.enclosing = order_b ? hd.n_objects - 1 : ~0u;
     K.enclosing_flat = (order_b && s->enclosing_flat) ? 1u : 0u;
+    K.cull_in_lds = s->cull_in_lds ? 1u : 0u;
     K.sky_fast = (K.enclosing_flat && s->sky_const) ? 1u : 0u;
     for (int c = 0; c < 3; c++) K.sky_rgb[c] = s->sky_rgb[c];
     memcpy(K.miss_color, hd.miss_color, sizeof K.miss_color);

@@ -29,6 +29,18 @@
 // Sphere geometry as the uniform object loops read it: 32 bytes, scalar-loaded (s_load_dwordx8).
 struct rt_geom { double ox, oy, oz, r2; };
 
+// A sphere's material as the workgroup's LDS copy holds it: what the kernel reads per hit, packed by the host from rt_sphere
+// (20 doubles instead of 24: 64 spheres + the fold state then fit 32 KB, i.e. five workgroups per CU instead of four).
+struct rt_mtl {
+  double origin[3];
+  double inv_r;                      // 1 / radius: the product kernel's normal is (h - origin) * inv_r
+  double albedo[5];
+  double specular_exponent;
+  double refract_index;
+  int32_t sampler_kind, texture;
+  double c[8];                       // colour: c[0..2] = mtl.color; checker: c[0..5] = its two colours, c[6..7] = its frequencies;
+};                                   // stars: c[6..7] = threshold and gain (rt_sphere.checker_freq)
+
 // Everything one launch needs, passed by value in the kernarg segment (scalar-loaded into
 // SGPRs: all of it is wave-uniform).
 struct rt_launch {
@@ -36,7 +48,7 @@ struct rt_launch {
   const rt_sphere *objects;          // n_objects records of 192 B (materials; staged into LDS per workgroup)
   const rt_geom *geom;               // n_objects compact geometry records for the scalar-loaded loops
   const rt_geom *geom_cam;           // anchored at the camera: {o - cam, |o - cam|^2 - r2} per sphere
-  const void *lds_image;             // [materials (n_objects x 192 B) | 16 texture descriptors | cull rectangles]: the workgroup's LDS image
+  const void *lds_image;             // [materials (n_objects x rt_mtl) | 16 texture descriptors | cull rectangles if cull_in_lds]: the workgroup's LDS image
   const rt_geom *cull;               // per sphere {x_lo, x_hi, y_lo, y_hi}: bounds of X/D, Y/D of the pixels whose line meets it
   const void *shadow_grid;           // per-light shadow grids (rt_api.hip: build_shadow_grid), or NULL when the scene is small
   const void *bounce_table;          // per (sphere a ray starts on, direction cell): bit set of the spheres it can meet, or NULL
@@ -65,6 +77,7 @@ struct rt_launch {
   uint32_t sky_fast;                 // ... and its colour is a constant: a wave whose primary rays all miss the loop spheres stores sky_rgb
   double sky_rgb[3];
   uint32_t enclosing_flat;           // that sphere neither lights nor spawns rays and its colour ignores the hit point: its test is skipped
+  uint32_t cull_in_lds;              // 1: few spheres (no shadow grid, no bounce table): the cull rectangles are part of the LDS image, the product launch takes the few-sphere kernel; 0: the many-sphere kernel, every lane fetches its sphere's rectangle from `cull` (HBM / L2)
   uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused

@@ -398,8 +398,8 @@ __device__ __forceinline__ rt_geom_pair rt_load_geom_pair32(geom_kptr tab, uint3
 }
 
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
-__device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere *mtl, const rt_texture_desc *tex,
-                                            [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull, [[maybe_unused]] uint32_t lane,
+__device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mtl, const rt_texture_desc *tex,
+                                            [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull_lds, [[maybe_unused]] const rt_geom cull0, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
                                             [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3],
                                             [[maybe_unused]] bool is_probe) {
@@ -413,6 +413,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
   const double eps = L.epsilon;
   const uint32_t NLOOP = L.n_loop;                      // spheres the per-ray loops walk: N, or N-1 with an enclosing sphere
   const uint32_t enc = L.enclosing;                      // device index of the enclosing sphere (== NLOOP), or ~0u
+  // where the primary-ray cull's rectangles are: the product kernels know at compile time (the host launches the many-sphere
+  // variant exactly for the scenes whose LDS image leaves them out), the strict and counting kernels ask the launch record
+  const bool cull_lds_on = (!RT_STRICT && !COUNT) ? !GRID : (L.cull_in_lds != 0u);
 #if RT_STRICT
   constexpr bool FOLD_FORWARD = false;
 #else
@@ -479,7 +482,19 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         [[maybe_unused]] const geom_kptr ga = (geom_kptr)L.geom_cam;
         for (uint32_t base = 0; base < NLOOP; base += 64u) {
           const uint32_t j = base + lane;
-          const rt_geom cr = cull[j < NLOOP ? j : 0u];                   // LDS: {x_lo, x_hi, y_lo, y_hi} in units of 1/D
+          // {x_lo, x_hi, y_lo, y_hi} in units of 1/D.  Few spheres: from the LDS image.  Many: one record per lane from HBM (L2) -
+          // the first 64 were fetched before the ray was generated (cull0), scenes of more spheres fetch the rest here
+          const uint32_t jj = j < NLOOP ? j : 0u;
+          double c0 = cull0.ox, c1 = cull0.oy, c2 = cull0.oz, c3 = cull0.r2;
+          // (explicit address spaces: the compiler otherwise selects the POINTER and issues one flat load for both cases)
+          if (cull_lds_on) {
+            const rt_geom __attribute__((address_space(3))) *g = (const rt_geom __attribute__((address_space(3))) *)cull_lds + jj;
+            c0 = g->ox; c1 = g->oy; c2 = g->oz; c3 = g->r2;
+          } else if (base != 0u) {
+            const rt_geom __attribute__((address_space(1))) *g = (const rt_geom __attribute__((address_space(1))) *)L.cull + jj;
+            c0 = g->ox; c1 = g->oy; c2 = g->oz; c3 = g->r2;
+          }
+          const rt_geom cr = rt_geom{c0, c1, c2, c3};
           const bool keep = (j < NLOOP) && (cr.ox * L.proj_d <= blk_x1) && (cr.oy * L.proj_d >= blk_x0) &&
                             (cr.oz * L.proj_d <= blk_y1) && (cr.r2 * L.proj_d >= blk_y0);
           unsigned long long m = __ballot(keep);
@@ -605,7 +620,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         }
 #endif
       } else {
-        const rt_sphere &m = mtl[hi];                 // LDS, per-lane index
+        const rt_mtl &m = mtl[hi];                    // LDS, per-lane index
         // A2 ext part for the closest hit only (main.js:440-447; pure, so deferring it is exact)
         const v3 h = mk(p.x + d.x * ht, p.y + d.y * ht, p.z + d.z * ht);
 #if RT_STRICT
@@ -613,7 +628,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
         const v3 n = unit(mk(h.x - m.origin[0], h.y - m.origin[1], h.z - m.origin[2]), &nlen);
 #else
         // the hit point lies on the sphere, so |h - o| is r up to the rounding of h: scale by the stored 1/r
-        const double inv_r = m.reserved;
+        const double inv_r = m.inv_r;
         const v3 n = mk((h.x - m.origin[0]) * inv_r, (h.y - m.origin[1]) * inv_r, (h.z - m.origin[2]) * inv_r);
 #endif
         const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
@@ -646,8 +661,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           rt_atan2_asin(-n.y, -n.x, -n.z, &t_at, &t_as);
           const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
           const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
-          const int c = to_int32_bit0(u * m.checker_freq[0]) ^ to_int32_bit0(v * m.checker_freq[1]);
-          col[0] = m.checker_color[c][0]; col[1] = m.checker_color[c][1]; col[2] = m.checker_color[c][2];
+          const int c = to_int32_bit0(u * m.c[6]) ^ to_int32_bit0(v * m.c[7]);
+          col[0] = m.c[3 * c]; col[1] = m.c[3 * c + 1]; col[2] = m.c[3 * c + 2];
         } else if (kind == RT_SAMPLER_STARS) {
           // the sample's index in the FRAME (not in this call's tiles), recomputed from the work-item id so that it
           // costs no register outside this branch; `path` is the node's position in the ray tree
@@ -658,9 +673,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_sphere 
           const unsigned long long pix = (unsigned long long)sy * (SS2 ? 2u * L.w : L.w) + sx;
           const uint32_t path = REFRACT ? tree_path : (1u << level);
           double c = star_uniform((uint32_t)pix, (uint32_t)(pix >> 32), path);
-          c = (c >= m.checker_freq[0]) ? 0.0 : c * m.checker_freq[1];     // main.js:137-138
+          c = (c >= m.c[6]) ? 0.0 : c * m.c[7];     // main.js:137-138
           col[0] = col[1] = col[2] = c;
-        } else { col[0] = m.color[0]; col[1] = m.color[1]; col[2] = m.color[2]; }
+        } else { col[0] = m.c[0]; col[1] = m.c[1]; col[2] = m.c[2]; }
 
         // general product kernel: the sampled colour waits in LDS (slots 10-12 of the lane's fold state) while the
         // lights are scanned: six registers fewer across the hottest loop, which is what lets this kernel fit
@@ -1071,16 +1086,35 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   //      cull rectangles, laid out exactly as the LDS copy), so a workgroup pays one memory latency, not three;
   //      the loads are issued first and land while the ray is being generated ----
   const uint32_t tid = threadIdx.x;
-  const uint32_t mtl_words = L.n_objects * (uint32_t)(sizeof(rt_sphere) / 8);
+  const uint32_t mtl_words = L.n_objects * (uint32_t)(sizeof(rt_mtl) / 8);
   const uint32_t tex_words = 16u * 2u;               // RT_MAX_TEXTURES descriptors of 16 B
-  const uint32_t cull_words = L.n_objects * 4u;       // per-sphere screen rectangles for the primary-ray cull
+  const bool cull_lds_on = (!RT_STRICT && !COUNT) ? !GRID : (L.cull_in_lds != 0u);      // (see trace_pixel)
+  const uint32_t cull_words = cull_lds_on ? L.n_objects * 4u : 0u;     // per-sphere screen rectangles of the primary-ray cull (few spheres)
   const uint32_t image_words = mtl_words + tex_words + cull_words;
   const double *__restrict__ image = (const double *)L.lds_image;
-  const double stage0 = (tid < image_words) ? image[tid] : 0.0;                   // 8 spheres: exactly one word per work-item
-  const rt_sphere *mtl = (const rt_sphere *)lds_raw;
+  // (8 spheres: exactly one word per work-item.  Scenes of many spheres - 64 are 1824 words - fetch up to RT_STAGE_DEPTH words
+  // per work-item with ALL of those loads in flight before the first is waited for: one memory latency per workgroup instead
+  // of one per 256 words; 64-sphere scenes -5 %, profiles/r02_ab_log.md.)
+  constexpr uint32_t RT_STAGE_DEPTH = GRID ? 8u : 1u;
+  const bool deep = GRID && image_words > 2u * RT_WG_THREADS;                      // workgroup-uniform
+  double stage[RT_STAGE_DEPTH];
+  stage[0] = (tid < image_words) ? image[tid] : 0.0;
+  if constexpr (GRID) {
+    if (deep) {
+#pragma unroll
+      for (uint32_t i = 1; i < RT_STAGE_DEPTH; i++) { const uint32_t k = tid + i * RT_WG_THREADS; stage[i] = (k < image_words) ? image[k] : 0.0; }
+    }
+  }
+  const rt_mtl *mtl = (const rt_mtl *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
-  const rt_geom *cull = (const rt_geom *)(lds_raw + mtl_words + tex_words);
+  const rt_geom *cull_lds = (const rt_geom *)(lds_raw + mtl_words + tex_words);
   double *acc = lds_raw + mtl_words + tex_words + cull_words + tid;   // fold state: 10 (general kernel: 13) x RT_WG_THREADS doubles, lane-major
+  // Many spheres: the primary-ray cull's rectangle of sphere `lane` (the wave's first 64 spheres) comes straight from HBM / L2,
+  // in flight while the ray is generated, and is no part of the LDS image: 64 spheres + the fold state then fit 32 KB, five
+  // workgroups per CU instead of four (64-sphere scenes -12 %; with 8 spheres the extra vector load costs 3 %, so few
+  // spheres keep their rectangles in the image)
+  rt_geom cull0 = rt_geom{0.0, 0.0, 0.0, 0.0};
+  if (!cull_lds_on) { const uint32_t lane0 = tid & 63u; cull0 = L.cull[lane0 < L.n_loop ? lane0 : 0u]; }
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
@@ -1118,9 +1152,17 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
-  // finish the staging (first use of LDS is the cull table inside trace_pixel)
-  if (tid < image_words) lds_raw[tid] = stage0;
-  for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
+  // finish the staging (first use of LDS: the cull table or the closest hit's material inside trace_pixel)
+  if (tid < image_words) lds_raw[tid] = stage[0];
+  uint32_t staged = RT_WG_THREADS;
+  if constexpr (GRID) {
+    if (deep) {
+#pragma unroll
+      for (uint32_t i = 1; i < RT_STAGE_DEPTH; i++) { const uint32_t k = tid + i * RT_WG_THREADS; if (k < image_words) lds_raw[k] = stage[i]; }
+      staged = RT_STAGE_DEPTH * RT_WG_THREADS;
+    }
+  }
+  for (uint32_t k = tid + staged; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   __syncthreads();
 
   // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)
@@ -1133,7 +1175,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #else
   const bool is_probe = false;
 #endif
-  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe);
+  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe);
 
   // ---- A10 RGBA8 store ----
   uint32_t tid2 = threadIdx.x;
@@ -1222,7 +1264,8 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
                   L->grid_y ? L->grid_y : (L->order ? 1u : L->n_tiles * L->rb_per_tile), L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
   // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
-  const bool grid_variant = !RT_STRICT && !count && (L->shadow_grid != nullptr || L->bounce_table != nullptr);
+  // (the host leaves the cull rectangles out of the LDS image exactly for the scenes that have a shadow grid or a bounce table)
+  const bool grid_variant = !RT_STRICT && !count && !L->cull_in_lds;
   if (grid_variant) {
 #if !RT_STRICT
     if (!refract) { if (!ss2) RT_CASE(false, false, false, true); else RT_CASE(false, false, true, true); }
