@@ -588,6 +588,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
       memcpy(dst + (size_t)NO * sizeof(rt_mtl), descs, sizeof descs);
       if (s->cull_in_lds) memcpy(dst + (size_t)NO * sizeof(rt_mtl) + sizeof descs, geom.data() + ord * per_order + 2 * (size_t)NO, (size_t)NO * sizeof(rt_geom));
     }
+    img.resize(img.size() + 4096u, 0);               // the many-sphere kernel reads whole 4 KB pieces (rt_kernel.hip staging)
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_lds_image, img.size());
     if (e == hipSuccess) e = hipMemcpy(s->d_lds_image, img.data(), img.size(), hipMemcpyHostToDevice);
   }

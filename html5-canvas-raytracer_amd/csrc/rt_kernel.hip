@@ -1092,18 +1092,22 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t cull_words = cull_lds_on ? L.n_objects * 4u : 0u;     // per-sphere screen rectangles of the primary-ray cull (few spheres)
   const uint32_t image_words = mtl_words + tex_words + cull_words;
   const double *__restrict__ image = (const double *)L.lds_image;
-  // (8 spheres: exactly one word per work-item.  Scenes of many spheres - 64 are 1824 words - fetch up to RT_STAGE_DEPTH words
-  // per work-item with ALL of those loads in flight before the first is waited for: one memory latency per workgroup instead
-  // of one per 256 words; 64-sphere scenes -5 %, profiles/r02_ab_log.md.)
-  constexpr uint32_t RT_STAGE_DEPTH = GRID ? 8u : 1u;
-  const bool deep = GRID && image_words > 2u * RT_WG_THREADS;                      // workgroup-uniform
-  double stage[RT_STAGE_DEPTH];
-  stage[0] = (tid < image_words) ? image[tid] : 0.0;
+  // Few spheres (8: exactly one word per work-item): one 8-byte load each, a loop for the rest.  The many-sphere variant (64
+  // spheres are 10.5 KB) moves 16 bytes per work-item and instruction, three 4 KB pieces unrolled with ALL their loads in flight
+  // before the first is waited for, the loads themselves unconditional (the host pads the buffer to whole pieces, so a piece
+  // that starts inside the image may be read to its end) behind a scalar test per piece: one memory latency per workgroup
+  // and ~a tenth of the instructions of a word-by-word loop (profiles/r02_ab_log.md).
+  typedef uint32_t __attribute__((ext_vector_type(4))) rt_u4;
+  constexpr uint32_t RT_STAGE_PIECES = 3u;
+  const uint32_t image_vec = image_words >> 1;                                     // 16-byte units (GRID: the image is whole units)
+  [[maybe_unused]] rt_u4 piece[RT_STAGE_PIECES];
+  [[maybe_unused]] double stage0 = 0.0;
   if constexpr (GRID) {
-    if (deep) {
+    const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
-      for (uint32_t i = 1; i < RT_STAGE_DEPTH; i++) { const uint32_t k = tid + i * RT_WG_THREADS; stage[i] = (k < image_words) ? image[k] : 0.0; }
-    }
+    for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) if (i * RT_WG_THREADS < image_vec) piece[i] = image4[tid + i * RT_WG_THREADS];
+  } else {
+    stage0 = (tid < image_words) ? image[tid] : 0.0;
   }
   const rt_mtl *mtl = (const rt_mtl *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
@@ -1153,16 +1157,19 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
   // finish the staging (first use of LDS: the cull table or the closest hit's material inside trace_pixel)
-  if (tid < image_words) lds_raw[tid] = stage[0];
-  uint32_t staged = RT_WG_THREADS;
   if constexpr (GRID) {
-    if (deep) {
+    rt_u4 *lds4 = (rt_u4 *)lds_raw;
+    const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
-      for (uint32_t i = 1; i < RT_STAGE_DEPTH; i++) { const uint32_t k = tid + i * RT_WG_THREADS; if (k < image_words) lds_raw[k] = stage[i]; }
-      staged = RT_STAGE_DEPTH * RT_WG_THREADS;
+    for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) {
+      const uint32_t k = tid + i * RT_WG_THREADS;
+      if (i * RT_WG_THREADS < image_vec && k < image_vec) lds4[k] = piece[i];
     }
+    for (uint32_t k = tid + RT_STAGE_PIECES * RT_WG_THREADS; k < image_vec; k += RT_WG_THREADS) lds4[k] = image4[k];     // more than 73 spheres
+  } else {
+    if (tid < image_words) lds_raw[tid] = stage0;
+    for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   }
-  for (uint32_t k = tid + staged; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   __syncthreads();
 
   // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-2 GPU call 32: where the 64-sphere kernel's instructions go: SQ_INSTS_VALU / SALU per wave of the ablation builds (test
+# builds, timing-only images) on the lcg64 scene at 3840x2160 with 2x2 samples; kernel ms of the same builds
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD
+cd /tmp
+for v in base nosampler noshadow nolight depth1 noshade; do
+  rm -rf /tmp/pmc_$v
+  RT_HIP_LIB=$R/build/ab/librt_hip_abl_$v.so RT_BENCH_NO_SETTLE=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/pmc_$v -- python3 $R/bench.py --scene lcg64 --steps 6 --warmup 1 --no-cpu-baseline --no-pmc > /tmp/pmc_$v.log 2>&1
+  python3 - $v <<'PY'
+import csv, glob, sys, collections
+v = sys.argv[1]
+acc = collections.defaultdict(list)
+for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % v, recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "rt_trace<false, false, true, true>" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(v, {k: round(sum(x) / len(x) / 518400.0, 1) for k, x in sorted(acc.items())}, "per wave", flush=True)
+PY
+done 2>&1 | tee $R/gpurun_out/r02_valu_by_section_lcg64.log
+cd $R
+for v in base nosampler noshadow nolight depth1 noshade; do
+  RT_HIP_LIB=$R/build/ab/librt_hip_abl_$v.so python3 bench.py --scene lcg64 --steps 200 --warmup 10 --no-cpu-baseline --no-pmc 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$v', d['roofline']['kernel_ms'])"
+done 2>&1 | tee -a $R/gpurun_out/r02_valu_by_section_lcg64.log
