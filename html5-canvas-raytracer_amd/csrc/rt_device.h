@@ -16,12 +16,12 @@
 #define RT_TILE_H 8
 
 // Shadow grid (product kernel, scenes with more than RT_SGRID_MIN_LOOP spheres in the loops): cells per axis of a
-// light's projective view of the scene; see build_shadow_grid in rt_api.hip for the buffer layout.
+// light's projective view of the scene; see build_shadow_grid in rt_tables.cpp for the buffer layout.
 #define RT_MAX_SCATTER 16u          /* frames of one rt_render_scatter_device call */
 #define RT_SGRID 32u
 #define RT_SGRID_MIN_LOOP 12u
 // Bounce table (same scenes): directions are binned on a cube map of RT_BGRID x RT_BGRID cells per face; see
-// build_bounce_table in rt_api.hip.
+// build_bounce_table in rt_tables.cpp.
 #define RT_BGRID 8u
 #define RT_BTABLE_MIN_LOOP 24u     /* measured: +10 % on the 64-sphere scene, -2 % on the reference's 14-sphere scene */
 #define RT_BCELLS (6u * RT_BGRID * RT_BGRID)
@@ -50,7 +50,7 @@ struct rt_launch {
   const rt_geom *geom_cam;           // anchored at the camera: {o - cam, |o - cam|^2 - r2} per sphere
   const void *lds_image;             // [materials (n_objects x rt_mtl) | 16 texture descriptors | cull rectangles if cull_in_lds]: the workgroup's LDS image
   const rt_geom *cull;               // per sphere {x_lo, x_hi, y_lo, y_hi}: bounds of X/D, Y/D of the pixels whose line meets it
-  const void *shadow_grid;           // per-light shadow grids (rt_api.hip: build_shadow_grid), or NULL when the scene is small
+  const void *shadow_grid;           // per-light shadow grids (rt_tables.cpp: build_shadow_grid), or NULL when the scene is small
   const void *bounce_table;          // per (sphere a ray starts on, direction cell): bit set of the spheres it can meet, or NULL
   const rt_geom *geom_light;         // anchored at light k: [k*n_objects + j] = {o_j - light_k, |o_j - light_k|^2 - r2_j}
   const rt_texture_desc *textures;   // texels_offset is relative to `texel_base`

@@ -536,7 +536,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             // Many spheres: a bounced ray starts ON the sphere it just hit (`hcode` still names it) and its direction
             // falls in one cell of a cube map.  The host stored, per (sphere, cell), the bit set of the spheres that
             // ANY ray leaving that sphere's ball in ANY direction of that cell can meet (conservative: angle between
-            // the cell and the line of centres against asin((r_i + r_j) / distance), rt_api.hip build_bounce_table).
+            // the cell and the line of centres against asin((r_i + r_j) / distance), rt_tables.cpp build_bounce_table).
             // The wave tests the UNION over its active lanes, walked like the shadow grid's cells (readlane + ballot,
             // correct under divergence), in index order, so the strict-< tie-break of the full scan is kept.
             const uint32_t from = (uint32_t)(hcode >> 1);

@@ -1,0 +1,32 @@
+// rt_tables.h — host-built tables of a scene (pure host logic, rt_tables.cpp); shared by rt_api.hip only.
+#ifndef RT_TABLES_H
+#define RT_TABLES_H
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "rt_device.h"
+
+namespace rt_tables {
+
+// {x_lo, x_hi, y_lo, y_hi}: bounds of X/D and Y/D over the pixels whose line of sight meets the sphere (infinite where unbounded)
+rt_geom cull_rect(const rt_scene_header *hd, const rt_sphere &o);
+
+// per-light grids of sphere bit sets for the shadow scans of many-sphere scenes (layout: rt_tables.cpp)
+std::vector<uint64_t> build_shadow_grid(const rt_sphere *objs, uint32_t n_loop, uint32_t n_lights, const double lights[][3]);
+
+// per (sphere, cube-map direction cell) bit sets of the spheres a ray leaving that sphere in that direction can meet
+std::vector<uint64_t> build_bounce_table(const rt_sphere *objs, uint32_t n_objects, uint32_t n_loop);
+
+// per sphere: its cull rectangle (scene order) and the cost weight of a tile that shows it (launch-table ranking)
+void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vector<rt_geom> *cull, std::vector<uint32_t> *weight);
+
+// the product kernel's launch table for `tiles` of a w x h frame (2 words per workgroup, XCD-contiguous layout); empty if the
+// launch is too large for the table
+std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight, uint32_t w, uint32_t h, uint32_t ss,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked);
+
+}  // namespace rt_tables
+
+#endif

@@ -15,8 +15,9 @@ COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -f
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=0 -ffp-contract=fast -c $SRC/rt_kernel.hip -o $T/kf.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=1 -ffp-contract=off -c $SRC/rt_kernel.hip -o $T/ks.o &
 /opt/rocm/bin/hipcc $COMMON $APITESTING $FLAGS -c $SRC/rt_api.hip -o $T/api.o &
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -Wall -I$SRC -x c++ -c $SRC/rt_tables.cpp -o $T/tables.o &
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/librt_hip_$NAME.so $T/api.o $T/kf.o $T/ks.o -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/librt_hip_$NAME.so $T/api.o $T/tables.o $T/kf.o $T/ks.o -ldl
 cp $T/kf.o $OUT/rt_kernel_fast_$NAME.o      # for profiles/kernel_resources.sh / isa_histogram.sh
 rm -rf $T
 echo built $OUT/librt_hip_$NAME.so

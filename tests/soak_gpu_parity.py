@@ -120,7 +120,28 @@ def main():
     t0 = time.time()
     tot = {k: {"channels": 0, "off_by_one": 0, "flipped_pixels": 0, "worst": 0, "scenes_with_flips": []} for k in ("fma", "strict")}
     pixels = 0
+    # a soak that is cut short (timeout's SIGTERM, a GPU box's limit) still reports what it covered
+    import signal
+    stop = {"now": False}
+    signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("now", True))
+    done = 0
+
+    def report(interrupted):
+        out = {"seeds": [args.first, args.first + done - 1], "pixels_per_kernel": pixels, "seconds": round(time.time() - t0, 1)}
+        if interrupted:
+            out["interrupted_after_scenes"] = done
+        for k, T in tot.items():
+            out[k] = {"off_by_one_channel_fraction": T["off_by_one"] / max(T["channels"], 1), "flipped_pixels": T["flipped_pixels"],
+                      "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
+                      "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"])}
+        text = json.dumps(out, indent=1)
+        if args.out:
+            open(args.out, "w").write(text)
+        return text
+
     for seed in range(args.first, args.first + args.seeds):
+        if stop["now"]:
+            break
         scene, w, h = draw_scene(seed, args.degenerate_lights, args.many_spheres)
         blob = rt_host.flatten_scene(scene)
         want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h * w, 4).astype(np.int16)
@@ -146,18 +167,13 @@ def main():
         finally:
             lib.rt_free_device(0, d)
             r.close()
-        if (seed - args.first + 1) % 50 == 0:
+        done += 1
+        if done % 50 == 0:
             print("seed %d: %d pixels, %.0f s; flipped fma=%d strict=%d" % (seed, pixels, time.time() - t0, tot["fma"]["flipped_pixels"],
                                                                            tot["strict"]["flipped_pixels"]), flush=True)
-    out = {"seeds": [args.first, args.first + args.seeds - 1], "pixels_per_kernel": pixels, "seconds": round(time.time() - t0, 1)}
-    for k, T in tot.items():
-        out[k] = {"off_by_one_channel_fraction": T["off_by_one"] / max(T["channels"], 1), "flipped_pixels": T["flipped_pixels"],
-                  "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
-                  "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"])}
-    text = json.dumps(out, indent=1)
-    print(text)
-    if args.out:
-        open(args.out, "w").write(text)
+        if done % 5000 == 0:
+            report(True)                                    # checkpoint: a killed run leaves its last 5000-scene mark behind
+    print(report(done < args.seeds))
 
 
 if __name__ == "__main__":

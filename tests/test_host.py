@@ -318,7 +318,7 @@ def _launch_table(lib, blob, w, h, tiles, ranked):
     ("lcg64", 4096, 1031, (24, 1, 2, 22)),        # supersample 2: 2 rows per workgroup, general tile split
     ("cfg1", 1, 1, (1, 0, 1, 1))])
 def test_launch_table_lists_every_block_exactly_once(built, scene, w, h, tiles):
-    """Host logic of the product kernel's launch table (csrc/rt_api.hip build_launch_table, through the rt_scene_launch_table
+    """Host logic of the product kernel's launch table (csrc/rt_tables.cpp build_launch_table, through the rt_scene_launch_table
     probe): whatever the order, the entries are exactly the blocks of the tile set - every (tile column, first frame row) once,
     with the band row the plain grid would have used and the number of rows inside the tile and the frame - and the ranked table
     is a permutation of the unranked one that never lists a dearer block after a cheaper one."""
