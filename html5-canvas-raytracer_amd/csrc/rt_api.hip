@@ -125,9 +125,10 @@ struct rt_scene_dev {
   double sky_rgb[3];
   // cost-ordered dispatch (dispatch_order below): per sphere its screen rectangle (X/D, Y/D bounds, scene order) and a weight,
   // and the order tables built so far, one per (frame size, tile set), kept on the device
+  std::vector<rt_sphere> host_objects;   // the scene's sphere records (scene order), for the launch table's sky marking
   std::vector<rt_geom> host_cull;
   std::vector<uint32_t> tile_weight;
-  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked; uint32_t *d_order; };
+  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky; uint32_t n_entries; uint32_t *d_order; };
   std::vector<order_entry> orders;
   std::mutex order_mu;
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
@@ -284,18 +285,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   rt_texture_desc descs[RT_MAX_TEXTURES];
   memset(descs, 0, sizeof descs);
   if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
-  // Enclosing sphere: every other sphere, every light and the camera strictly inside it, with a margin far
-  // above rounding.  Such a sphere never shadows anything and is the closest hit only of rays that hit
-  // nothing else, which lets the product kernel take it out of the per-ray loops (exact, not approximate).
-  s->enclosing = ~0u;
-  for (uint32_t e = 0; e < hd->n_objects && s->enclosing == ~0u; e++) {
-    const double re = sqrt(ob[e].r2), lim = re * (1.0 - 1e-6);
-    auto dist_to = [&](const double q[3]) { const double x = q[0] - ob[e].origin[0], y = q[1] - ob[e].origin[1], z = q[2] - ob[e].origin[2]; return sqrt(x * x + y * y + z * z); };
-    bool ok = re > 0.0 && dist_to(hd->cam_origin) < lim;
-    for (uint32_t k = 0; k < hd->n_lights && ok; k++) ok = dist_to(s->lights[k]) < lim;
-    for (uint32_t j = 0; j < hd->n_objects && ok; j++) if (j != e) ok = dist_to(ob[j].origin) + sqrt(ob[j].r2) < lim;
-    if (ok && hd->n_objects > 1) s->enclosing = e;
-  }
+  s->enclosing = enclosing_sphere(hd, ob, s->lights);     // (rt_tables.cpp)
   s->enclosing_flat = false;
   if (s->enclosing != ~0u) {
     const rt_sphere &sk = ob[s->enclosing];
@@ -318,6 +308,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
   // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
   scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
+  s->host_objects.assign(ob, ob + hd->n_objects);
   // device copy of the blob: the `reserved` slot of each sphere record carries 1/r for the product kernel
   std::vector<uint8_t> patched((const uint8_t *)blob, (const uint8_t *)blob + bytes);
   {
@@ -500,14 +491,17 @@ extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h,
 
 namespace {
 const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked, bool *temporary) {
+                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, uint32_t *n_entries, bool *temporary) {
   *temporary = false;
   std::lock_guard<std::mutex> lk(s->order_mu);
   for (const rt_scene_dev::order_entry &e : s->orders)
     if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
-        e.n_tiles == tiles->n_tiles && e.ranked == ranked)
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky) {
+      *n_entries = e.n_entries;
       return e.d_order;
-  const std::vector<uint32_t> table = build_launch_table(s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, ranked);
+    }
+  const std::vector<uint32_t> table = build_launch_table(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile,
+                                                         proj_w, proj_h, proj_d, ranked, mark_sky, s->enclosing, n_entries);
   if (table.empty()) { fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile); return nullptr; }
   uint32_t *d = nullptr;
   hipError_t e = hipMalloc((void **)&d, table.size() * 4u);
@@ -517,7 +511,7 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
   // been rendered with 64 different (frame size, tile set) pairs gets per-call tables from then on, freed by the caller once
   // its launches have drained.
   if (s->orders.size() >= 64u) { *temporary = true; return d; }
-  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, d});
+  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, mark_sky, *n_entries, d});
   return d;
 }
 
@@ -542,9 +536,15 @@ extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w,
   const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
   if ((uint64_t)tiles->n_tiles * rb_per_tile > 65535u) return fail(RT_ERR_INVALID, "too many row blocks");
   const double pw = (double)w * ss / 2.0, ph = (double)h * ss / 2.0, pd = pw / tan(hd->fov_deg * M_PI / 180.0 / 2.0);
-  const std::vector<uint32_t> table = build_launch_table(cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, ranked != 0);
+  // (bit 1 of `ranked`: also mark the workgroups no sphere but the enclosing one can show in, as a launch of a constant-background scene does)
+  double lights[RT_MAX_LIGHTS][3];
+  memset(lights, 0, sizeof lights);
+  if (hd->n_lights) memcpy(lights, (const uint8_t *)blob + hd->lights_offset, hd->n_lights * 24u);
+  const uint32_t sky_sphere = enclosing_sphere(hd, ob, lights);
+  uint32_t n_entries = 0;
+  const std::vector<uint32_t> table = build_launch_table(hd, ob, cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, sky_sphere, &n_entries);
   if (table.empty()) return fail(RT_ERR_INVALID, "a launch of this size is beyond the launch table");
-  *n_workgroups = tiles_x * tiles->n_tiles * rb_per_tile;
+  *n_workgroups = n_entries;
   if (out_entries) memcpy(out_entries, table.data(), table.size() * sizeof(uint32_t));
   return RT_OK;
 }
@@ -715,7 +715,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     K.sky_fast = (K.enclosing_flat && s->sky_const) ? 1u : 0u;
     for (int c = 0; c < 3; c++) K.sky_rgb[c] = s->sky_rgb[c];
     memcpy(K.miss_color, hd.miss_color, sizeof K.miss_color);
-    if (K.sky_fast) {
+    if (!plain && s->enclosing == ~0u && hd.segs > 0) {
+      // no enclosing sphere at all: a primary ray that meets nothing is the miss colour (main.js:231), a constant as well
+      K.sky_fast = 1u;
+      memcpy(K.sky_rgb, hd.miss_color, sizeof K.sky_rgb);
+    } else if (K.sky_fast) {
       // A flat sky of constant colour needs no hit record at all: "met nothing in the loops" IS "met the sky", whose pixel term
       // is the constant the host evaluated - so for the product kernel that constant takes the place of the miss colour
       // (main.js:231 is unreachable in such a scene: the sky encloses every ray) and the sphere leaves the kernel's view.
@@ -777,10 +781,16 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   } temp_table;
   if (!strict_main) {
     bool temporary = false;
-    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, &temporary);
+    // workgroups no sphere can show in are marked in the table and store the background constant without tracing (rt_tables.cpp);
+    // the counting variant traces them like any other (its counters are what the caller wants)
+    static const bool no_sky_tiles = RT_TEST_ENV("RT_NO_SKY_TILES") != nullptr;   // A/B switch (test build)
+    const bool mark_sky = L.sky_fast != 0u && !count && !no_sky_tiles;
+    uint32_t n_entries = 0;
+    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky, &n_entries, &temporary);
     if (!L.order) return RT_ERR_DEVICE;
     if (temporary) { temp_table.p = (void *)L.order; temp_table.st = stream; }
-    L.order_n8 = (L.tiles_x * tiles->n_tiles * L.rb_per_tile + 7u) / 8u;
+    L.order_n8 = (n_entries + 7u) / 8u;
+    L.grid_x = n_entries; L.grid_y = 1u;               // one workgroup per table entry (runs of sky blocks share one)
   }
   int err = (strict_main ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, lds_for(strict_main), stream);
   // Centre row / centre column of a sample grid with an ODD number of rows / columns.  The primary rays there have a direction

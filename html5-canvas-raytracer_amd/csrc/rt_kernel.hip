@@ -315,7 +315,7 @@ typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 // Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
 // again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
 // the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
-struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid; bool valid; };
+struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid, run; bool valid, sky; };
 #if RT_STRICT
 template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
@@ -337,6 +337,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
   P.valid = P.valid && (P.px - L.win_x0 < L.win_w) && (P.frow - L.win_y0 < L.win_h);
   P.rows_valid = 0u;                                   // (product kernel only)
+  P.sky = false; P.run = 1u;
   return P;
 }
 #else
@@ -360,7 +361,9 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   if (!SS2) { P.px = tile_x * RT_TILE_W + wave * 8u + (lane & 7u); P.trow = lane >> 3; }
   else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = q >> 3; }
   P.frow = frow0 + P.trow;
-  P.lrow = e1 + P.trow;
+  P.lrow = (e1 & 0xffffffu) + P.trow;
+  P.sky = (e1 >> 31) != 0u;                            // workgroup-uniform: no sphere can show in these blocks (rt_tables.cpp) ...
+  P.run = ((e1 >> 24) & 127u) + 1u;                    // ... a run of this many 32-pixel blocks, starting at tile_x
   P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
   P.valid = (P.px < L.w) && (P.trow < rows_valid);
   return P;
@@ -1127,6 +1130,14 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #if !RT_STRICT
   if (P0.rows_valid == 0u) return;                     // workgroup-uniform: a block wholly past its tile's or the frame's last row
 #endif
+  double rgb[3];
+  uint32_t cnt[3] = {0u, 0u, 0u};
+  // A workgroup the host marked as showing no sphere (rt_tables.cpp: the cull's own comparisons, made once for the workgroup's
+  // box) stores the background constant: no staging, no barrier, no ray, no cull.  (The staging loads issued above are simply
+  // never waited for.)  45 % of the headline's workgroups.
+  if (P0.sky) {
+    rgb[0] = L.sky_rgb[0]; rgb[1] = L.sky_rgb[1]; rgb[2] = L.sky_rgb[2];
+  } else {
   const uint32_t px = P0.px, frow = P0.frow, sub = P0.sub;
   const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px;
   const uint32_t sy = SS2 ? 2u * frow + (sub >> 1) : frow;
@@ -1155,8 +1166,6 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const v3 ray = mk(rawray.x * rl, rawray.y * rl, rawray.z * rl);
 #endif
 
-  double rgb[3];
-  uint32_t cnt[3] = {0u, 0u, 0u};
   // finish the staging (first use of LDS: the cull table or the closest hit's material inside trace_pixel)
   if constexpr (GRID) {
     rt_u4 *lds4 = (rt_u4 *)lds_raw;
@@ -1184,6 +1193,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const bool is_probe = false;
 #endif
   trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe);
+  }
 
   // ---- A10 RGBA8 store ----
   uint32_t tid2 = threadIdx.x;
@@ -1207,6 +1217,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     packed += __shfl_xor(packed, 2);
     rgbw = (((packed & 1023u) + 2u) >> 2) | ((((packed >> 10) & 1023u) + 2u) >> 2 << 8) | ((((packed >> 20) & 1023u) + 2u) >> 2 << 16);
   }
+  // A sky entry of the launch table stands for a RUN of consecutive 32-pixel blocks of one row block (rt_tables.cpp): the
+  // workgroup stores the same constant into each of them; every other workgroup stores its one block.
+#if RT_STRICT
+  const uint32_t n_run = 1u;
+#else
+  const uint32_t n_run = P1.sky ? P1.run : 1u;
+#endif
   if (!L.rgb24 && L.scatter && !SS2) {                 // workgroup-uniform
     // Peer stores want whole lines: a wave's 8x8 block is eight 32-byte pieces, one per row, and memory on the far side
     // of an xGMI link has no L2 of ours in front of it to merge them.  So the workgroup transposes its 32x8 tile through
@@ -1218,17 +1235,27 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     const uint32_t xr = tid2 & 31u, rr = tid2 >> 5;     // this work-item's pixel of the tile in row-major order
     const uint32_t v = tile[2u * (((xr >> 3) << 6) + (rr << 3) + (xr & 7u))];
     const uint32_t lane2 = tid2 & 63u;
-    const uint32_t px2 = P1.px - ((tid2 >> 6) * 8u + (lane2 & 7u)) + xr;
     const uint32_t dr = rr - (lane2 >> 3);              // row of the tile: difference in wrap-around arithmetic
     const uint32_t trow2 = P1.trow + dr, frow2 = P1.frow + dr;
+    uint32_t px2 = P1.px - ((tid2 >> 6) * 8u + (lane2 & 7u)) + xr;
+    for (uint32_t t = 0; t < n_run; t++, px2 += RT_TILE_W) {
 #if RT_STRICT
-    const bool row_ok2 = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h) && trow2 < L.tile_rows && frow2 < L.h;
+      const bool row_ok2 = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h) && trow2 < L.tile_rows && frow2 < L.h;
 #else
-    const bool row_ok2 = trow2 < P1.rows_valid;        // rows of the block inside its tile and the frame (from the table entry)
+      const bool row_ok2 = trow2 < P1.rows_valid;      // rows of the block inside its tile and the frame (from the table entry)
 #endif
-    if (row_ok2 && px2 < L.w) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
+      if (row_ok2 && px2 < L.w) out[(size_t)frow2 * L.w + px2] = v | 0xff000000u;
+    }
   } else if (!L.rgb24) {                               // wave-uniform
-    if (valid && P1.sub == 0u) out[(size_t)orow * L.w + P1.px] = rgbw | 0xff000000u;
+    uint32_t pxq = P1.px;
+    for (uint32_t t = 0; t < n_run; t++, pxq += RT_TILE_W) {
+#if RT_STRICT
+      const bool validq = valid;
+#else
+      const bool validq = (pxq < L.w) && (P1.trow < P1.rows_valid);
+#endif
+      if (validq && P1.sub == 0u) out[(size_t)orow * L.w + pxq] = rgbw | 0xff000000u;
+    }
   } else {
     // RT_FLAG_RGB24: the 8 pixels a wave holds of one row are 24 bytes = 6 words.  Word j of the group takes its bytes
     // from pixels p = j + j/3 and p + 1, shifted by (j mod 3) bytes; lanes j < 6 of the group store.  w % 4 == 0 (host
@@ -1240,15 +1267,17 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     const uint32_t pn = (j < 6u) ? p + 1u : p;         // lanes 6,7 store nothing; keep their source lane inside the group
     const uint32_t lo = __shfl(rgbw, SS2 ? (p << 2) : p), hi = __shfl(rgbw, SS2 ? (pn << 2) : pn);
     const uint32_t word = (lo >> sh) | (hi << (24u - sh));
-    const uint32_t x0 = P1.px - j;                     // first pixel of the group (a multiple of 8)
-    const uint32_t in_row = (x0 + 8u <= L.w) ? 6u : ((x0 + 4u <= L.w) ? 3u : 0u);
+    uint32_t x0 = P1.px - j;                           // first pixel of the group (a multiple of 8)
+    for (uint32_t t = 0; t < n_run; t++, x0 += RT_TILE_W) {
+      const uint32_t in_row = (x0 + 8u <= L.w) ? 6u : ((x0 + 4u <= L.w) ? 3u : 0u);
 #if RT_STRICT
-    // a window's columns are whole 8-pixel groups (rt_api.hip), so the group's first pixel decides
-    const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h) && (x0 - L.win_x0 < L.win_w) && (P1.frow - L.win_y0 < L.win_h);
+      // a window's columns are whole 8-pixel groups (rt_api.hip), so the group's first pixel decides
+      const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h) && (x0 - L.win_x0 < L.win_w) && (P1.frow - L.win_y0 < L.win_h);
 #else
-    const bool row_ok = P1.trow < P1.rows_valid;
+      const bool row_ok = P1.trow < P1.rows_valid;
 #endif
-    if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
+      if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
+    }
   }
 
   if (COUNT) {

@@ -47,6 +47,22 @@ rt_geom cull_rect(const rt_scene_header *hd, const rt_sphere &o) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------ enclosing sphere (host logic)
+// The sphere that has every other sphere, every light and the camera strictly inside it, with a margin far
+// above rounding (a skybox), or ~0u.  Such a sphere never shadows anything and is the closest hit only of rays that hit
+// nothing else, which lets the product kernel take it out of the per-ray loops (exact, not approximate).
+uint32_t enclosing_sphere(const rt_scene_header *hd, const rt_sphere *ob, const double lights[][3]) {
+  for (uint32_t e = 0; e < hd->n_objects; e++) {
+    const double re = sqrt(ob[e].r2), lim = re * (1.0 - 1e-6);
+    auto dist_to = [&](const double q[3]) { const double x = q[0] - ob[e].origin[0], y = q[1] - ob[e].origin[1], z = q[2] - ob[e].origin[2]; return sqrt(x * x + y * y + z * z); };
+    bool ok = re > 0.0 && dist_to(hd->cam_origin) < lim;
+    for (uint32_t k = 0; k < hd->n_lights && ok; k++) ok = dist_to(lights[k]) < lim;
+    for (uint32_t j = 0; j < hd->n_objects && ok; j++) if (j != e) ok = dist_to(ob[j].origin) + sqrt(ob[j].r2) < lim;
+    if (ok && hd->n_objects > 1) return e;
+  }
+  return ~0u;
+}
+
 // ------------------------------------------------------------------------------------ shadow grids (host logic)
 // Buffer layout (all 8-byte units): NL headers of 16 doubles {frame rows x'[3], y'[3], z'[3], gx0, gy0, 1/cell_w,
 // 1/cell_h, pad[3]}, then per light (RT_SGRID*RT_SGRID + 1) cells of `words` uint64 each: bit j of a cell = sphere j
@@ -218,10 +234,13 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 // picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
 // (`cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns 2 words per entry, 8 * ceil(n/8) entries;
 // empty on a launch that is too large for the table)
-std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight, uint32_t w, uint32_t h, uint32_t ss,
-                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked) {
+std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
+                                         uint32_t w, uint32_t h, uint32_t ss,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
+                                         bool mark_sky, uint32_t sky_sphere, uint32_t *n_entries) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
+  if (n_entries) *n_entries = 0;
   if (tiles_x > 2048u || n64 >= (1ull << 31) || n64 == 0) return {};   // (the caller reports it)
   const uint32_t n = (uint32_t)n64;
   const uint32_t rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                                // output rows a workgroup covers
@@ -254,16 +273,93 @@ std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const
     }
     for (uint32_t c : cost) cmax = c > cmax ? c : cmax;
   }
+  // Sky tiles.  In a scene whose background is a constant (a flat enclosing sphere of plain colour, or no enclosing sphere at all:
+  // the miss colour) a workgroup none of whose primary rays can meet a sphere stores that constant and nothing else.  Which
+  // workgroups those are is decided here, geometrically and with margins far above the kernel's rounding: the rays of a
+  // workgroup's samples lie inside the circular cone around the box's centre direction that contains its four corner
+  // directions (half-angle alpha); a sphere with centre C (seen from the camera) and radius R is met by SOME ray of that cone
+  // only if the angle between the cone's axis and C is at most alpha + asin(R / |C|).  (The cull rectangles cannot decide this:
+  // they bound the pixels whose LINE meets a sphere, and the line of a sky pixel meets the ground sphere behind the camera.)
+  // Marked workgroups get bit 31 of their second word set and skip staging, ray generation, cull and trace (rt_kernel.hip);
+  // `sky_sphere` (scene order, or ~0u) is the enclosing sphere, which the product kernel's loops never test.
+  std::vector<uint8_t> touched;
+  const double as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
+               as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
+  if (mark_sky && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 && std::isfinite(proj_d) && proj_d > 0.0) {
+    touched.assign(n, 0);
+    struct ball { double c[3], sin_b, cos_b; bool everywhere; };
+    std::vector<ball> balls;
+    for (uint32_t j = 0; j < hd->n_objects; j++) {
+      if (j == sky_sphere) continue;
+      ball B;
+      for (int c = 0; c < 3; c++) B.c[c] = ob[j].origin[c] - hd->cam_origin[c];
+      const double len = sqrt(B.c[0] * B.c[0] + B.c[1] * B.c[1] + B.c[2] * B.c[2]), R = sqrt(ob[j].r2) * (1.0 + 1e-7);
+      B.everywhere = !(ob[j].r2 > 0.0) || !std::isfinite(len) || !std::isfinite(R) || !(len > R * (1.0 + 1e-7));      // camera inside / on / unknown
+      if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= len; B.sin_b = R / len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
+      balls.push_back(B);
+    }
+    for (uint32_t y = 0; y < ny; y++) {
+      const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
+      const double row0 = ((double)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + (double)rb * rows_per_wg) * ss;
+      const double Y1 = (proj_h - 0.5) - row0, Y0 = Y1 - (double)(wg_h - 1u);
+      for (uint32_t x = 0; x < tiles_x; x++) {
+        const double X0 = (double)((uint64_t)x * wg_w) + (0.5 - proj_w), X1 = X0 + (double)(wg_w - 1u);
+        const double cx[4] = {X0, X1, X0, X1}, cy[4] = {Y0, Y0, Y1, Y1};
+        double u[4][3], ax[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 4; k++) {                      // the reference's ray: (s0 * X, s1 * Y, s2 * D), main.js:186-193 (q1)
+          const double dx = as0 * cx[k], dy = as1 * cy[k], dz = as2 * proj_d, l = sqrt(dx * dx + dy * dy + dz * dz);
+          u[k][0] = dx / l; u[k][1] = dy / l; u[k][2] = dz / l;
+          for (int c = 0; c < 3; c++) ax[c] += u[k][c];
+        }
+        const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        bool hit = !(al > 1e-3);                           // (a box wider than a half space: never at these fields of view)
+        double cos_a = 1.0;
+        if (!hit) {
+          for (int c = 0; c < 3; c++) ax[c] /= al;
+          for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
+          cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
+          hit = !(cos_a > 1e-3);
+        }
+        const double sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
+        for (size_t j = 0; j < balls.size() && !hit; j++) {
+          const ball &B = balls[j];
+          if (B.everywhere) { hit = true; break; }
+          const double cos_ab = cos_a * B.cos_b - sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
+          const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2];
+          if (!(cs < cos_ab - 1e-7)) hit = true;                            // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
+        }
+        touched[(size_t)y * tiles_x + x] = hit ? 1 : 0;
+      }
+    }
+  }
+  // The entries: one per workgroup.  A block that shows a sphere is an entry of its own; consecutive sky blocks of one row
+  // block are ONE entry (a run of up to RT_SKY_RUN_MAX blocks: its workgroup stores the constant into each).
+  constexpr uint32_t RT_SKY_RUN_MAX = 32u;
+  struct item { uint32_t y, x, run, cost; };
+  std::vector<item> items;
+  items.reserve(n);
+  for (uint32_t y = 0; y < ny; y++)
+    for (uint32_t x = 0; x < tiles_x;) {
+      const size_t at = (size_t)y * tiles_x + x;
+      if (touched.empty() || touched[at]) { items.push_back({y, x, 0u, rank ? cost[at] : 1u}); x++; continue; }
+      uint32_t run = 1;
+      while (x + run < tiles_x && run < RT_SKY_RUN_MAX && !touched[at + run]) run++;
+      items.push_back({y, x, run, 1u});                  // (sky: base cost, last in the ranked order)
+      x += run;
+    }
+  const uint32_t n_items = (uint32_t)items.size();
+  if (n_entries) *n_entries = n_items;
   // counting sort, dearest first; equal costs keep the grid's order (neighbours stay neighbours)
   std::vector<uint32_t> start(cmax + 2u, 0u);
   if (rank) {
-    for (uint32_t c : cost) start[cmax - c + 1u]++;
+    for (const item &it : items) start[cmax - it.cost + 1u]++;
     for (uint32_t c = 0; c <= cmax; c++) start[c + 1u] += start[c];
   }
-  const uint32_t n8 = (n + 7u) / 8u;                    // workgroup b's entry sits at (b % 8) * n8 + b / 8: one contiguous part per XCD
+  const uint32_t n8 = (n_items + 7u) / 8u;              // workgroup b's entry sits at (b % 8) * n8 + b / 8: one contiguous part per XCD
   std::vector<uint32_t> table((size_t)n8 * 8u * 2u, 0u);
   uint32_t next = 0;
-  for (uint32_t y = 0; y < ny; y++) {
+  for (const item &it : items) {
+    const uint32_t y = it.y;
     const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
     const uint32_t trow0 = rb * rows_per_wg;                                             // first row of the block inside its tile
     const uint64_t frow0 = (uint64_t)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + trow0;
@@ -274,12 +370,11 @@ std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const
       if (h - frow0 < rows_valid) rows_valid = (uint32_t)(h - frow0);
     }
     const uint32_t w0 = (rows_valid << 11) | ((uint32_t)(frow0 < h ? frow0 : 0u) << 15);        // frow0 < 65536 + 8: 17 bits
-    const uint32_t w1 = tile_i * tiles->tile_rows + trow0;
-    for (uint32_t x = 0; x < tiles_x; x++) {
-      const uint32_t b = rank ? start[cmax - cost[(size_t)y * tiles_x + x]]++ : next++;      // the workgroup that renders this tile
-      const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
-      table[2u * at] = w0 | x; table[2u * at + 1u] = w1;
-    }
+    const uint32_t w1 = tile_i * tiles->tile_rows + trow0;                                    // < 2^24 (checked by the caller): bits 24..31 are free
+    const uint32_t b = rank ? start[cmax - it.cost]++ : next++;                               // the workgroup that renders this entry
+    const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
+    table[2u * at] = w0 | it.x;
+    table[2u * at + 1u] = w1 | (it.run ? (0x80000000u | ((it.run - 1u) << 24)) : 0u);
   }
   return table;
 }

@@ -13,6 +13,9 @@ namespace rt_tables {
 // {x_lo, x_hi, y_lo, y_hi}: bounds of X/D and Y/D over the pixels whose line of sight meets the sphere (infinite where unbounded)
 rt_geom cull_rect(const rt_scene_header *hd, const rt_sphere &o);
 
+// the sphere that strictly contains every other sphere, every light and the camera (a skybox), or ~0u
+uint32_t enclosing_sphere(const rt_scene_header *hd, const rt_sphere *ob, const double lights[][3]);
+
 // per-light grids of sphere bit sets for the shadow scans of many-sphere scenes (layout: rt_tables.cpp)
 std::vector<uint64_t> build_shadow_grid(const rt_sphere *objs, uint32_t n_loop, uint32_t n_lights, const double lights[][3]);
 
@@ -23,9 +26,14 @@ std::vector<uint64_t> build_bounce_table(const rt_sphere *objs, uint32_t n_objec
 void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vector<rt_geom> *cull, std::vector<uint32_t> *weight);
 
 // the product kernel's launch table for `tiles` of a w x h frame (2 words per workgroup, XCD-contiguous layout); empty if the
-// launch is too large for the table
-std::vector<uint32_t> build_launch_table(const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight, uint32_t w, uint32_t h, uint32_t ss,
-                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked);
+// launch is too large for the table.  mark_sky: set bit 31 of the second word of every workgroup none of whose primary rays can meet a
+// sphere other than `sky_sphere` (scene order; ~0u: none) - the kernel stores the background constant there and skips everything else;
+// consecutive marked blocks of a row block share ONE entry (run length - 1 in bits 24..30); `ob` = the scene's sphere records
+// (host copy, scene order); *n_entries = the number of entries = workgroups of the launch
+std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
+                                         uint32_t w, uint32_t h, uint32_t ss,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
+                                         bool mark_sky, uint32_t sky_sphere, uint32_t *n_entries);
 
 }  // namespace rt_tables
 

@@ -172,7 +172,9 @@ int rt_scene_bounce_candidates(const void *scene_blob, size_t blob_bytes, uint32
  * 8-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in this call's output band}, stored at index
  * (b % 8) * ceil(n / 8) + b / 8.  With `ranked` the blocks are listed dearest first (a cost estimate from the spheres' screen
  * rectangles), which is the order the hardware then hands them out in.  out_entries: 16 * ceil(n / 8) words, or NULL to ask
- * for *n_workgroups only. */
+ * for *n_workgroups only.  Bit 1 of `ranked` (value 2): also set bit 31 of the second word of every workgroup that no sphere can
+ * show in (scenes whose background is a constant: a flat enclosing sphere of plain colour, or none), as the product launch does:
+ * those workgroups store the background and skip the trace. */
 int rt_scene_launch_table(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
                           uint32_t *out_entries, uint32_t *n_workgroups);
 

@@ -307,8 +307,86 @@ def _launch_table(lib, blob, w, h, tiles, ranked):
     for b in range(n.value):
         at = (b % 8) * n8 + b // 8                           # one contiguous part of the table per XCD
         e0, e1 = out[2 * at], out[2 * at + 1]
-        entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1))      # tile_x, rows_valid, first frame row, first band row
-    return entries
+        entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1 & 0xffffff) + (((e1 >> 31), ((e1 >> 24) & 127) + 1) if (int(ranked) & 2) else ()))
+    return entries                                            # tile_x, rows_valid, first frame row, first band row [, sky flag, run of blocks]
+
+
+@pytest.mark.parametrize("scene,w,h,tiles,min_share", [
+    ("h8", 3840, 2160, (2160, 0, 1, 1), 0.40),     # the headline: 45 % of the workgroups are sky
+    ("h8", 1001, 333, (16, 1, 3, 7), 0.2),        # ragged size, interleaved tiles
+    ("default14", 640, 360, (360, 0, 1, 1), 0.1),
+    ("lcg64", 512, 256, (256, 0, 1, 1), 0.2),      # supersample 2: 64 x 4 samples per workgroup
+    ("cfg1", 256, 256, (256, 0, 1, 1), 0.2)])      # no enclosing sphere: the miss colour is the background
+def test_launch_table_sky_marks_are_conservative(built, scene, w, h, tiles, min_share):
+    """Workgroups marked as sky in the launch table (bit 31 of the second word; the kernel stores the background constant there
+    and traces nothing): every marked workgroup is checked sample by sample here - corners, edges and a random interior
+    subset, all of them for small frames - with the reference's own ray (main.js:186-193) and the exact line-sphere
+    discriminant in binary64: no ray may come within a relative 1e-9 of meeting any sphere but the enclosing one.  And a
+    sensible share of the frame is marked."""
+    import math
+    import random
+    lib = rt_host.load_library()
+    sc = rt_host.load_scene(scene)
+    blob = rt_host.flatten_scene(sc)
+    ss = sc.get("supersample", 1)
+    rows_per_wg = 2 if ss == 2 else 8
+    entries = _launch_table(lib, blob, w, h, tiles, 3)
+    objs = sc["objects"]
+    cam = sc["camera"]
+    o = cam["origin"]
+    asum = [cam["axisX"][k] + cam["axisY"][k] + cam["axisZ"][k] for k in range(3)]
+
+    def dist(a, b):
+        return math.sqrt(sum((a[i] - b[i]) ** 2 for i in range(3)))
+    enclosing = None
+    for e, q in enumerate(objs):
+        lim = math.sqrt(q["r2"]) * (1 - 1e-6)
+        if len(objs) > 1 and dist(o, q["origin"]) < lim and all(dist(l, q["origin"]) < lim for l in sc["lights"]) and \
+           all(dist(p["origin"], q["origin"]) + math.sqrt(p["r2"]) < lim for j, p in enumerate(objs) if j != e):
+            enclosing = e
+            break
+    W, H = w * ss, h * ss
+    pw, ph = W / 2.0, H / 2.0
+    pd = pw / math.tan(sc.get("fovDeg", 60) * math.pi / 180 / 2)
+    wg_w, wg_h = 32 * ss, rows_per_wg * ss
+    balls = [([q["origin"][k] - o[k] for k in range(3)], q["r2"]) for j, q in enumerate(objs) if j != enclosing]
+    rng = random.Random(7)
+    marked = live = 0
+    exhaustive = w * h <= 256 * 256
+    # the entries cover every block of the tile set exactly once: an ordinary entry one block, a sky entry a run of them
+    tile_rows, first, stride, n_tiles = tiles
+    rb = (tile_rows + rows_per_wg - 1) // rows_per_wg
+    covered = {}
+    for tile_x, valid, frow0, lrow, sky, run in entries:
+        assert run == 1 or sky
+        for t in range(run):
+            key = (tile_x + t, lrow)
+            assert key not in covered and tile_x + t < (w + 31) // 32
+            covered[key] = 1
+    assert len(covered) == ((w + 31) // 32) * n_tiles * rb
+    blocks = [(tile_x + t, valid, frow0, sky) for tile_x, valid, frow0, _lrow, sky, run in entries for t in range(run)]
+    for tile_x, valid, frow0, sky in blocks:
+        if not valid:
+            continue
+        live += 1
+        if not sky:
+            continue
+        marked += 1
+        if not exhaustive and rng.random() > 0.03:           # large frames: a 3 % sample of the marked blocks
+            continue
+        xs = list(range(wg_w)) if exhaustive else sorted({0, wg_w - 1, wg_w // 2} | {rng.randrange(wg_w) for _ in range(5)})
+        ys = list(range(wg_h)) if exhaustive else sorted({0, wg_h - 1} | {rng.randrange(wg_h) for _ in range(2)})
+        for iy in ys:
+            for ix in xs:
+                sx, sy = tile_x * wg_w + ix, frow0 * ss + iy
+                d = [asum[0] * (sx - pw + 0.5), asum[1] * (ph - sy - 0.5), asum[2] * pd]
+                dd = sum(c * c for c in d)
+                for C3, r2 in balls:
+                    tca = sum(d[k] * C3[k] for k in range(3))
+                    cc = sum(c * c for c in C3)
+                    # the ray meets the ball iff tca > 0 (or the origin is inside) and tca^2 >= dd * (cc - r2)
+                    assert cc > r2 and (tca <= 0 or tca * tca < dd * (cc - r2) * (1 - 1e-9)), (scene, tile_x, frow0, ix, iy)
+    assert marked >= min_share * live, (scene, marked, live)
 
 
 @pytest.mark.parametrize("scene,w,h,tiles", [
