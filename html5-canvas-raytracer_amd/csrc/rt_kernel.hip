@@ -349,12 +349,13 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
 template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  typedef const unsigned long long __attribute__((address_space(4))) *order_kptr;
+  typedef uint32_t __attribute__((ext_vector_type(4))) rt_entry;                                     // 16 bytes (rt_tables.h: RT_ENTRY_WORDS)
+  typedef const rt_entry __attribute__((address_space(4))) *order_kptr;
   // entry of workgroup b at (b % 8) * ceil(n / 8) + b / 8: workgroups are dealt round-robin over the 8 XCDs (speed only, never
   // correctness), so each XCD's L2 reads one contiguous eighth of the table instead of every line of it
   const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
-  const unsigned long long e64 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 3));   // s_load_dwordx2
-  const uint32_t e0 = (uint32_t)e64, e1 = (uint32_t)(e64 >> 32);
+  const rt_entry e4 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 4));   // s_load_dwordx4
+  const uint32_t e0 = e4.x, e1 = e4.y;
   const uint32_t tile_x = e0 & 2047u, rows_valid = (e0 >> 11) & 15u, frow0 = e0 >> 15;
   rt_pixel P;
   P.sub = 0u;
@@ -367,6 +368,16 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
   P.valid = (P.px < L.w) && (P.trow < rows_valid);
   return P;
+}
+#endif
+
+#if !RT_STRICT
+// Word 2 of this workgroup's launch-table entry: per light, the 16-bit set of loop-order spheres that can shadow a primary hit of
+// its block (rt_tables.cpp), or ~0u.  Read again where it is used - the primary node's lighting - instead of being kept in a
+// scalar register across the cull and the search (the kernel has none to spare).
+__device__ __forceinline__ uint32_t rt_entry_shadow_masks(const rt_launch &L) {
+  const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
+  return *(const uint32_t __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 4) + 8u);
 }
 #endif
 
@@ -588,6 +599,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           if (i < NLOOP) { const rt_geom g0 = RT_LOAD(geom, i); RT_GENERIC(i, g0) }
         }
       }
+      [[maybe_unused]] const bool primary_node = searched;       // wave-uniform: this node is the primary ray's
       searched = false;
       // The enclosing sphere (every other sphere, light and the camera strictly inside it: a skybox) is
       // kept LAST in the device tables and outside the loops above: it can only be the closest hit of a
@@ -697,6 +709,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         if (a1 > 0.0 || a2 > 0.0) {
 #endif
           double li = L.light_intensity;                               // shared across lights (q2)
+#if !RT_STRICT
+          [[maybe_unused]] uint32_t smask = ~0u;
+          if constexpr (!GRID && !COUNT) { if (primary_node) smask = rt_entry_shadow_masks(L); }
+#endif
           for (uint32_t k = 0; k < NL; k++) {
             double llen;
             // light k from the kernarg segment through a 32-bit byte offset (scalar load with an SGPR offset)
@@ -829,6 +845,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               if (li != 0.0) {
                 uint32_t j = 0;
 #if !RT_STRICT
+                // Primary hits of a block whose table entry says that NO sphere can stand between the block's hit points and light k
+                // (rt_tables.cpp, shadow masks; most floor blocks): the scan is skipped.  Any other set takes the ordinary scan, which
+                // tests everything (a scan over just the named spheres would cost the kernel its 96th register).
+                bool masked = false;
+                if constexpr (!GRID) masked = primary_node && k < 2u && ((smask >> (16u * k)) & 0xffffu) == 0u;
+                if (!masked) {
                 if constexpr (!GRID) {
                   if (NS >= 2u) { const rt_geom g0 = gp_first.a, g1 = gp_first.b; RT_SHADOW_U(0u, g0) RT_SHADOW_U(1u, g1) j = 2u; }
                 }
@@ -839,6 +861,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
                 if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
+#if !RT_STRICT
+                }
+#endif
               }
             } else
             if (COUNT || li != 0.0) {                  // li == 0 on entry (an earlier light was blocked) cannot change

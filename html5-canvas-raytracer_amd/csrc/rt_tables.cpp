@@ -237,7 +237,7 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
                                          const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, uint32_t *n_entries) {
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, const double lights[][3], uint32_t *n_entries) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
   if (n_entries) *n_entries = 0;
@@ -282,22 +282,39 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
   // they bound the pixels whose LINE meets a sphere, and the line of a sky pixel meets the ground sphere behind the camera.)
   // Marked workgroups get bit 31 of their second word set and skip staging, ray generation, cull and trace (rt_kernel.hip);
   // `sky_sphere` (scene order, or ~0u) is the enclosing sphere, which the product kernel's loops never test.
+  // Shadow masks (few spheres, at most two lights; `shadow_masks`).  For the same box the host also knows WHERE its primary hits
+  // can lie - on candidate sphere i at distances t(c) = c - sqrt(c^2 - k), c = d.C, which over the cone is the interval between
+  // t at the largest and at the smallest c, so inside the ball around the cone's axis point at the mid distance with radius^2 =
+  // (dt/2)^2 + 2 t2 m (1 - cos alpha) - and therefore which spheres can stand between such a point and light k at all: sphere j
+  // only if the angle between (Q - L) and (C_j - L) is at most asin(rho / |Q - L|) + asin(R_j / |C_j - L|) and its nearest point
+  // is not beyond the patch.  The union over the box's candidate spheres, per light, is a 16-bit set of loop-order sphere
+  // indices; the kernel's PRIMARY hits scan only those (rt_kernel.hip).  0xffffffff = no statement: scan everything.
   std::vector<uint8_t> touched;
+  std::vector<uint32_t> smask;
   const double as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
                as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
-  if (mark_sky && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 && std::isfinite(proj_d) && proj_d > 0.0) {
-    touched.assign(n, 0);
-    struct ball { double c[3], sin_b, cos_b; bool everywhere; };
+  const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
+  const bool want_masks = shadow_masks && n_loop <= 16u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
+  if ((mark_sky || want_masks) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
+      std::isfinite(proj_d) && proj_d > 0.0) {
+    if (mark_sky) touched.assign(n, 0);
+    if (want_masks) smask.assign(n, 0xffffffffu);
+    struct ball { double c[3], o[3], len, R, k, sin_b, cos_b; uint32_t loop; bool everywhere; };
     std::vector<ball> balls;
     for (uint32_t j = 0; j < hd->n_objects; j++) {
       if (j == sky_sphere) continue;
       ball B;
-      for (int c = 0; c < 3; c++) B.c[c] = ob[j].origin[c] - hd->cam_origin[c];
-      const double len = sqrt(B.c[0] * B.c[0] + B.c[1] * B.c[1] + B.c[2] * B.c[2]), R = sqrt(ob[j].r2) * (1.0 + 1e-7);
-      B.everywhere = !(ob[j].r2 > 0.0) || !std::isfinite(len) || !std::isfinite(R) || !(len > R * (1.0 + 1e-7));      // camera inside / on / unknown
-      if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= len; B.sin_b = R / len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
+      for (int c = 0; c < 3; c++) { B.o[c] = ob[j].origin[c]; B.c[c] = ob[j].origin[c] - hd->cam_origin[c]; }
+      B.len = sqrt(B.c[0] * B.c[0] + B.c[1] * B.c[1] + B.c[2] * B.c[2]);
+      B.R = sqrt(ob[j].r2) * (1.0 + 1e-7);
+      B.k = B.len * B.len - B.R * B.R;
+      B.loop = (sky_sphere != ~0u && j > sky_sphere) ? j - 1u : j;       // index in the product kernel's loop order (enclosing sphere last)
+      B.everywhere = !(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7));      // camera inside / on / unknown
+      B.sin_b = B.cos_b = 0.0;
+      if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= B.len; B.sin_b = B.R / B.len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
       balls.push_back(B);
     }
+    std::vector<uint32_t> cand;
     for (uint32_t y = 0; y < ny; y++) {
       const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
       const double row0 = ((double)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + (double)rb * rows_per_wg) * ss;
@@ -312,23 +329,59 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
           for (int c = 0; c < 3; c++) ax[c] += u[k][c];
         }
         const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-        bool hit = !(al > 1e-3);                           // (a box wider than a half space: never at these fields of view)
+        bool hit = !(al > 1e-3), doubt = hit;              // (a box wider than a half space: never at these fields of view)
         double cos_a = 1.0;
         if (!hit) {
           for (int c = 0; c < 3; c++) ax[c] /= al;
           for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
           cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
-          hit = !(cos_a > 1e-3);
+          hit = doubt = !(cos_a > 1e-3);
         }
         const double sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
-        for (size_t j = 0; j < balls.size() && !hit; j++) {
+        cand.clear();
+        for (size_t j = 0; j < balls.size() && !doubt; j++) {
           const ball &B = balls[j];
-          if (B.everywhere) { hit = true; break; }
+          if (B.everywhere) { hit = doubt = true; break; }
           const double cos_ab = cos_a * B.cos_b - sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
           const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2];
-          if (!(cs < cos_ab - 1e-7)) hit = true;                            // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
+          if (!(cs < cos_ab - 1e-7)) { hit = true; cand.push_back((uint32_t)j); }   // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
         }
-        touched[(size_t)y * tiles_x + x] = hit ? 1 : 0;
+        const size_t at = (size_t)y * tiles_x + x;
+        if (mark_sky) touched[at] = hit ? 1 : 0;
+        if (!want_masks || doubt || cand.empty()) continue;
+        uint32_t mk[2] = {0u, 0u};
+        bool ok = true;
+        for (uint32_t ci : cand) {
+          const ball &B = balls[ci];
+          // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
+          const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
+          const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
+          const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), sqrt(fmax(B.k, 0.0)));
+          if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo)) { ok = false; break; }
+          const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
+          if (!(t2 >= t1) || !(t1 >= 0.0) || !std::isfinite(t2)) { ok = false; break; }
+          const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
+          const double Q[3] = {hd->cam_origin[0] + m * ax[0], hd->cam_origin[1] + m * ax[1], hd->cam_origin[2] + m * ax[2]};
+          for (uint32_t k = 0; k < hd->n_lights; k++) {
+            const double V[3] = {Q[0] - lights[k][0], Q[1] - lights[k][1], Q[2] - lights[k][2]};
+            const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+            for (size_t j = 0; j < balls.size(); j++) {
+              if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
+              const ball &O = balls[j];
+              const double W[3] = {O.o[0] - lights[k][0], O.o[1] - lights[k][1], O.o[2] - lights[k][2]};
+              const double w = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+              bool inc;
+              if (!(w > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !std::isfinite(w) || !std::isfinite(dist)) inc = true;     // light inside the occluder or the patch
+              else {
+                const double s1 = rho / dist, s2 = O.R / w, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
+                const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * w);
+                inc = !(cosang < cos12 - 1e-7) && (w - O.R <= (dist + rho) * (1.0 + 1e-7));
+              }
+              if (inc) mk[k] |= 1u << O.loop;
+            }
+          }
+        }
+        if (ok) smask[at] = mk[0] | (mk[1] << 16);
       }
     }
   }
@@ -356,7 +409,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
     for (uint32_t c = 0; c <= cmax; c++) start[c + 1u] += start[c];
   }
   const uint32_t n8 = (n_items + 7u) / 8u;              // workgroup b's entry sits at (b % 8) * n8 + b / 8: one contiguous part per XCD
-  std::vector<uint32_t> table((size_t)n8 * 8u * 2u, 0u);
+  std::vector<uint32_t> table((size_t)n8 * 8u * RT_ENTRY_WORDS, 0u);
   uint32_t next = 0;
   for (const item &it : items) {
     const uint32_t y = it.y;
@@ -373,8 +426,9 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
     const uint32_t w1 = tile_i * tiles->tile_rows + trow0;                                    // < 2^24 (checked by the caller): bits 24..31 are free
     const uint32_t b = rank ? start[cmax - it.cost]++ : next++;                               // the workgroup that renders this entry
     const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
-    table[2u * at] = w0 | it.x;
-    table[2u * at + 1u] = w1 | (it.run ? (0x80000000u | ((it.run - 1u) << 24)) : 0u);
+    table[RT_ENTRY_WORDS * at] = w0 | it.x;
+    table[RT_ENTRY_WORDS * at + 1u] = w1 | (it.run ? (0x80000000u | ((it.run - 1u) << 24)) : 0u);
+    table[RT_ENTRY_WORDS * at + 2u] = smask.empty() ? 0xffffffffu : smask[(size_t)it.y * tiles_x + it.x];     // (word 3: reserved)
   }
   return table;
 }

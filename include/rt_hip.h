@@ -169,12 +169,15 @@ int rt_scene_bounce_candidates(const void *scene_blob, size_t blob_bytes, uint32
 
 /* Host-logic probe (no GPU): the launch table of the product kernel for `tiles` of the w x h frame (scene supersample 1 or 2).
  * The kernel runs on a flat grid; workgroup b renders the 32-pixel-wide, 8-row (2 with supersample 2) block described by its
- * 8-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in this call's output band}, stored at index
- * (b % 8) * ceil(n / 8) + b / 8.  With `ranked` the blocks are listed dearest first (a cost estimate from the spheres' screen
- * rectangles), which is the order the hardware then hands them out in.  out_entries: 16 * ceil(n / 8) words, or NULL to ask
- * for *n_workgroups only.  Bit 1 of `ranked` (value 2): also set bit 31 of the second word of every workgroup that no sphere can
- * show in (scenes whose background is a constant: a flat enclosing sphere of plain colour, or none), as the product launch does:
- * those workgroups store the background and skip the trace. */
+ * 16-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in this call's output band | (run - 1) << 24 |
+ * sky << 31, shadow masks, reserved}, stored at index (b % 8) * ceil(n / 8) + b / 8.  `ranked` is a bit set:
+ *   1  the blocks are listed dearest first (a cost estimate from the spheres' screen rectangles), which is the order the
+ *      hardware then hands them out in;
+ *   2  blocks none of whose primary rays can meet a sphere are marked (sky = 1) and consecutive ones of a row block share one
+ *      entry (run of blocks), as the launch of a scene with a constant background does: their workgroup stores the background;
+ *   4  word 2 = per light (16 bits each) the loop-order spheres that can shadow a primary hit of the block at all (scenes of at
+ *      most 16 loop spheres and 2 lights; 0xffffffff = no statement).
+ * out_entries: 32 * ceil(n / 8) words, or NULL to ask for *n_workgroups (= n, the number of entries) only. */
 int rt_scene_launch_table(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
                           uint32_t *out_entries, uint32_t *n_workgroups);
 

@@ -301,14 +301,15 @@ def _launch_table(lib, blob, w, h, tiles, ranked):
     n = C.c_uint32()
     assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), None, C.byref(n)) == 0, lib.rt_last_error()
     n8 = (n.value + 7) // 8
-    out = (C.c_uint32 * (16 * n8))()
+    out = (C.c_uint32 * (32 * n8))()                         # 4 words per entry
     assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), out, C.byref(n)) == 0
     entries = []
     for b in range(n.value):
         at = (b % 8) * n8 + b // 8                           # one contiguous part of the table per XCD
-        e0, e1 = out[2 * at], out[2 * at + 1]
-        entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1 & 0xffffff) + (((e1 >> 31), ((e1 >> 24) & 127) + 1) if (int(ranked) & 2) else ()))
-    return entries                                            # tile_x, rows_valid, first frame row, first band row [, sky flag, run of blocks]
+        e0, e1, e2 = out[4 * at], out[4 * at + 1], out[4 * at + 2]
+        entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1 & 0xffffff) + (((e1 >> 31), ((e1 >> 24) & 127) + 1) if (int(ranked) & 2) else ()) +
+                       ((e2,) if (int(ranked) & 4) else ()))
+    return entries                                            # tile_x, rows_valid, first frame row, first band row [, sky flag, run of blocks] [, shadow masks]
 
 
 @pytest.mark.parametrize("scene,w,h,tiles,min_share", [
@@ -387,6 +388,91 @@ def test_launch_table_sky_marks_are_conservative(built, scene, w, h, tiles, min_
                     # the ray meets the ball iff tca > 0 (or the origin is inside) and tca^2 >= dd * (cc - r2)
                     assert cc > r2 and (tca <= 0 or tca * tca < dd * (cc - r2) * (1 - 1e-9)), (scene, tile_x, frow0, ix, iy)
     assert marked >= min_share * live, (scene, marked, live)
+
+
+@pytest.mark.parametrize("scene,w,h,sample,min_empty", [
+    ("h8", 3840, 2160, 0.02, 0.3),                 # the headline: most floor blocks have no possible occluder
+    ("h8", 640, 360, 0.3, 0.05),
+    ("cfg2", 480, 270, 0.5, 0.0),
+    ("default14", 640, 360, 0.3, 0.0),             # 13 loop spheres: host logic only (its kernel variant uses the shadow grids)
+    ("cfg1", 128, 128, 1.0, 0.0)])
+def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, min_empty):
+    """Shadow masks of the launch table (word 2 of an entry: per light, the loop-order spheres that can shadow a PRIMARY hit of
+    the block at all; the kernel skips the scan of a light whose set is empty): for sampled blocks every sample's primary hit
+    is computed here with the exact discriminant, its shadow ray to each light is intersected with every other sphere, and
+    every sphere that blocks (main.js:293-304: a root in (epsilon, light distance)) must be in the block's set."""
+    import math
+    import random
+    lib = rt_host.load_library()
+    sc = rt_host.load_scene(scene)
+    blob = rt_host.flatten_scene(sc)
+    ss = sc.get("supersample", 1)
+    assert ss == 1
+    entries = _launch_table(lib, blob, w, h, (h, 0, 1, 1), 4)
+    objs = sc["objects"]
+    cam = sc["camera"]
+    o = cam["origin"]
+    asum = [cam["axisX"][k] + cam["axisY"][k] + cam["axisZ"][k] for k in range(3)]
+    eps = sc.get("epsilon", 0.001)
+
+    def dist(a, b):
+        return math.sqrt(sum((a[i] - b[i]) ** 2 for i in range(3)))
+    enclosing = None
+    for e, q in enumerate(objs):
+        lim = math.sqrt(q["r2"]) * (1 - 1e-6)
+        if len(objs) > 1 and dist(o, q["origin"]) < lim and all(dist(l, q["origin"]) < lim for l in sc["lights"]) and \
+           all(dist(p["origin"], q["origin"]) + math.sqrt(p["r2"]) < lim for j, p in enumerate(objs) if j != e):
+            enclosing = e
+            break
+    loop_of = {j: (j - 1 if (enclosing is not None and j > enclosing) else j) for j in range(len(objs)) if j != enclosing}
+    pw, ph = w / 2.0, h / 2.0
+    pd = pw / math.tan(sc.get("fovDeg", 60) * math.pi / 180 / 2)
+
+    def hit_t(org, d, q):                                     # main.js:420-439 for a unit direction
+        L3 = [q["origin"][k] - org[k] for k in range(3)]
+        tca = sum(d[k] * L3[k] for k in range(3))
+        d2 = sum(c * c for c in L3) - tca * tca
+        if d2 > q["r2"]:
+            return math.inf
+        thc = math.sqrt(q["r2"] - d2)
+        t0, t1 = tca - thc, tca + thc
+        t = t1 if t0 < eps else t0
+        return math.inf if t < eps else t
+    rng = random.Random(11)
+    stated = empty = 0
+    for tile_x, valid, frow0, _lrow, smask in entries:
+        if not valid or smask == 0xffffffff:
+            continue
+        stated += 1
+        empty += (smask == 0)
+        if rng.random() > sample:
+            continue
+        for iy in sorted({0, valid - 1, rng.randrange(valid)}):
+            for ix in sorted({0, 31, rng.randrange(32), rng.randrange(32)}):
+                sx, sy = tile_x * 32 + ix, frow0 + iy
+                if sx >= w:
+                    continue
+                d = [asum[0] * (sx - pw + 0.5), asum[1] * (ph - sy - 0.5), asum[2] * pd]
+                n = math.sqrt(sum(c * c for c in d))
+                d = [c / n for c in d]
+                best, bi = math.inf, None
+                for j, q in enumerate(objs):
+                    t = hit_t(o, d, q)
+                    if t < best:
+                        best, bi = t, j
+                if bi is None or bi == enclosing:
+                    continue                                  # sky (flat: no lighting) or a miss
+                hp = [o[k] + d[k] * best for k in range(3)]
+                for k, lt in enumerate(sc["lights"]):
+                    sv = [lt[c] - hp[c] for c in range(3)]
+                    llen = math.sqrt(sum(c * c for c in sv))
+                    sv = [c / llen for c in sv]
+                    for j, q in enumerate(objs):
+                        if j == bi or j == enclosing:
+                            continue
+                        if hit_t(hp, sv, q) < llen:
+                            assert (smask >> (16 * k)) & (1 << loop_of[j]), (scene, tile_x, frow0, ix, iy, k, j, hex(smask))
+    assert stated > 0 and empty >= min_empty * stated, (scene, stated, empty)
 
 
 @pytest.mark.parametrize("scene,w,h,tiles", [
