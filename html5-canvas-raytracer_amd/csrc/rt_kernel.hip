@@ -846,23 +846,30 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
                 uint32_t j = 0;
 #if !RT_STRICT
                 // Primary hits of a block whose table entry says that NO sphere can stand between the block's hit points and light k
-                // (rt_tables.cpp, shadow masks; most floor blocks): the scan is skipped.  Any other set takes the ordinary scan, which
-                // tests everything (a scan over just the named spheres would cost the kernel its 96th register).
+                // (rt_tables.cpp, shadow masks; most floor blocks): the scan is skipped.  Any other set takes the ordinary scan minus
+                // the pairs neither sphere of which is in the set (a loop over just the named spheres would cost the kernel its
+                // 96th register).
                 bool masked = false;
-                if constexpr (!GRID) masked = primary_node && k < 2u && ((smask >> (16u * k)) & 0xffffu) == 0u;
+                [[maybe_unused]] uint32_t mk = ~0u;                     // pairs of spheres neither of which can shadow are skipped as well
+                if constexpr (!GRID) { if (primary_node && k < 2u) mk = (smask >> (16u * k)) | 0xffff0000u; masked = (mk & 0xffffu) == 0u; }
                 if (!masked) {
                 if constexpr (!GRID) {
-                  if (NS >= 2u) { const rt_geom g0 = gp_first.a, g1 = gp_first.b; RT_SHADOW_U(0u, g0) RT_SHADOW_U(1u, g1) j = 2u; }
+                  if (NS >= 2u) { if (mk & 3u) { const rt_geom g0 = gp_first.a, g1 = gp_first.b; RT_SHADOW_U(0u, g0) RT_SHADOW_U(1u, g1) } j = 2u; }
                 }
 #endif
                 for (; j + 2 <= NS; j += 2) {
+#if !RT_STRICT
+                  if (!GRID && ((mk >> j) & 3u) == 0u) continue;
+#endif
                   const rt_geom_pair gp = rt_load_geom_pair32(gl, glo + j);
                   const rt_geom g0 = gp.a, g1 = gp.b;
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
-                if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
 #if !RT_STRICT
+                if (j < NS && (GRID || ((mk >> j) & 1u))) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
                 }
+#else
+                if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
 #endif
               }
             } else
