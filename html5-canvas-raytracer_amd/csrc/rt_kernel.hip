@@ -315,7 +315,7 @@ typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 // Which pixel (or sample) a work-item owns.  Evaluated twice from the work-item id — before the ray is generated and
 // again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
 // the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
-struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid, run; bool valid, sky; };
+struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid, run, cand; bool valid, sky; };
 #if RT_STRICT
 template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
   P.valid = P.valid && (P.px - L.win_x0 < L.win_w) && (P.frow - L.win_y0 < L.win_h);
   P.rows_valid = 0u;                                   // (product kernel only)
-  P.sky = false; P.run = 1u;
+  P.sky = false; P.run = 1u; P.cand = 0u;
   return P;
 }
 #else
@@ -365,6 +365,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.lrow = (e1 & 0xffffffu) + P.trow;
   P.sky = (e1 >> 31) != 0u;                            // workgroup-uniform: no sphere can show in these blocks (rt_tables.cpp) ...
   P.run = ((e1 >> 24) & 127u) + 1u;                    // ... a run of this many 32-pixel blocks, starting at tile_x
+  P.cand = e4.w;                                       // the (at most two) loop spheres the block's primary rays can meet, or 0: cull
   P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
   P.valid = (P.px < L.w) && (P.trow < rows_valid);
   return P;
@@ -416,7 +417,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull_lds, [[maybe_unused]] const rt_geom cull0, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
                                             [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3],
-                                            [[maybe_unused]] bool is_probe) {
+                                            [[maybe_unused]] bool is_probe, [[maybe_unused]] uint32_t cand_host) {
 #ifdef RT_TESTING
   uint32_t probe_n = 0;                                  // test build: nodes of this sample's ray tree recorded so far
   double probe_li = 0.0;
@@ -494,6 +495,19 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         // A wave of sky pixels tests nothing; a wave of floor pixels tests the floor.  The cull only prunes, so the strict
         // kernel uses it too (with the reference's own discriminant for the survivors) and stays bit-identical.
         [[maybe_unused]] const geom_kptr ga = (geom_kptr)L.geom_cam;
+#if !RT_STRICT
+        // A block for which the host names at most two spheres its primary rays can meet at all (word 3 of its table entry;
+        // a floor block names the floor) tests those and skips the cull.
+        if (cand_host != 0u) {
+          uint32_t m = cand_host;
+          while (m) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const rt_geom g0 = RT_LOAD(ga, i);
+            RT_ANCHORED(i, g0)
+          }
+        } else
+#endif
         for (uint32_t base = 0; base < NLOOP; base += 64u) {
           const uint32_t j = base + lane;
           // {x_lo, x_hi, y_lo, y_hi} in units of 1/D.  Few spheres: from the LDS image.  Many: one record per lane from HBM (L2) -
@@ -1224,7 +1238,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #else
   const bool is_probe = false;
 #endif
-  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe);
+  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe, P0.cand);
   }
 
   // ---- A10 RGBA8 store ----

@@ -290,7 +290,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
   // is not beyond the patch.  The union over the box's candidate spheres, per light, is a 16-bit set of loop-order sphere
   // indices; the kernel's PRIMARY hits scan only those (rt_kernel.hip).  0xffffffff = no statement: scan everything.
   std::vector<uint8_t> touched;
-  std::vector<uint32_t> smask;
+  std::vector<uint32_t> smask, cands;      // cands: the (at most two) loop spheres a block's primary rays can meet at all, or 0 = no statement
   const double as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
                as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
   const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
@@ -298,7 +298,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
   if ((mark_sky || want_masks) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
       std::isfinite(proj_d) && proj_d > 0.0) {
     if (mark_sky) touched.assign(n, 0);
-    if (want_masks) smask.assign(n, 0xffffffffu);
+    if (want_masks) { smask.assign(n, 0xffffffffu); cands.assign(n, 0u); }
     struct ball { double c[3], o[3], len, R, k, sin_b, cos_b; uint32_t loop; bool everywhere; };
     std::vector<ball> balls;
     for (uint32_t j = 0; j < hd->n_objects; j++) {
@@ -349,6 +349,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
         const size_t at = (size_t)y * tiles_x + x;
         if (mark_sky) touched[at] = hit ? 1 : 0;
         if (!want_masks || doubt || cand.empty()) continue;
+        if (cand.size() <= 2u && n_loop <= 32u) { uint32_t cm = 0u; for (uint32_t ci : cand) cm |= 1u << balls[ci].loop; cands[at] = cm; }
         uint32_t mk[2] = {0u, 0u};
         bool ok = true;
         for (uint32_t ci : cand) {
@@ -428,7 +429,8 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
     const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
     table[RT_ENTRY_WORDS * at] = w0 | it.x;
     table[RT_ENTRY_WORDS * at + 1u] = w1 | (it.run ? (0x80000000u | ((it.run - 1u) << 24)) : 0u);
-    table[RT_ENTRY_WORDS * at + 2u] = smask.empty() ? 0xffffffffu : smask[(size_t)it.y * tiles_x + it.x];     // (word 3: reserved)
+    table[RT_ENTRY_WORDS * at + 2u] = smask.empty() ? 0xffffffffu : smask[(size_t)it.y * tiles_x + it.x];
+    table[RT_ENTRY_WORDS * at + 3u] = cands.empty() ? 0u : cands[(size_t)it.y * tiles_x + it.x];
   }
   return table;
 }

@@ -306,9 +306,9 @@ def _launch_table(lib, blob, w, h, tiles, ranked):
     entries = []
     for b in range(n.value):
         at = (b % 8) * n8 + b // 8                           # one contiguous part of the table per XCD
-        e0, e1, e2 = out[4 * at], out[4 * at + 1], out[4 * at + 2]
+        e0, e1, e2, e3 = out[4 * at], out[4 * at + 1], out[4 * at + 2], out[4 * at + 3]
         entries.append((e0 & 2047, (e0 >> 11) & 15, e0 >> 15, e1 & 0xffffff) + (((e1 >> 31), ((e1 >> 24) & 127) + 1) if (int(ranked) & 2) else ()) +
-                       ((e2,) if (int(ranked) & 4) else ()))
+                       ((e2, e3) if (int(ranked) & 4) else ()))
     return entries                                            # tile_x, rows_valid, first frame row, first band row [, sky flag, run of blocks] [, shadow masks]
 
 
@@ -400,7 +400,8 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
     """Shadow masks of the launch table (word 2 of an entry: per light, the loop-order spheres that can shadow a PRIMARY hit of
     the block at all; the kernel skips the scan of a light whose set is empty): for sampled blocks every sample's primary hit
     is computed here with the exact discriminant, its shadow ray to each light is intersected with every other sphere, and
-    every sphere that blocks (main.js:293-304: a root in (epsilon, light distance)) must be in the block's set."""
+    every sphere that blocks (main.js:293-304: a root in (epsilon, light distance)) must be in the block's set; and the sphere
+    that is hit must be among the block's primary candidates (word 3) when the entry names them."""
     import math
     import random
     lib = rt_host.load_library()
@@ -440,7 +441,7 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
         return math.inf if t < eps else t
     rng = random.Random(11)
     stated = empty = 0
-    for tile_x, valid, frow0, _lrow, smask in entries:
+    for tile_x, valid, frow0, _lrow, smask, cands in entries:
         if not valid or smask == 0xffffffff:
             continue
         stated += 1
@@ -462,6 +463,8 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                         best, bi = t, j
                 if bi is None or bi == enclosing:
                     continue                                  # sky (flat: no lighting) or a miss
+                # word 3: the (at most two) spheres the block's primary rays can meet at all - the kernel then skips its cull
+                assert cands == 0 or (cands >> loop_of[bi]) & 1, (scene, tile_x, frow0, ix, iy, bi, hex(cands))
                 hp = [o[k] + d[k] * best for k in range(3)]
                 for k, lt in enumerate(sc["lights"]):
                     sv = [lt[c] - hp[c] for c in range(3)]
