@@ -224,15 +224,16 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 
 
 // The product kernel's launch table, and cost-ordered dispatch.  The product kernel runs on a FLAT grid and reads, per workgroup,
-// one 8-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band} (rt_kernel.hip:
-// rt_pixel_of) - the tile / row-block arithmetic of the plain grid done once on the host.  That also puts the ORDER in which
+// one 16-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band | (run - 1) << 24 | sky << 31,
+// shadow masks, primary candidates} (rt_kernel.hip: rt_pixel_of) - the tile / row-block arithmetic of the plain grid done once on
+// the host, plus what the host can tell a block in advance (sky blocks, shadow masks, candidates: below).  That also puts the ORDER in which
 // the hardware hands the tiles out in the host's hands.  In grid order a frame ends on whatever lies at the bottom right -
 // for the reference's scenes the floor and the sphere that both reflects and refracts, the dearest tiles of all - and the
 // last of them run alone on an otherwise idle chip.  For launches of many workgroups the host therefore ranks the tiles by a
 // cost estimate (the weights of the spheres whose screen rectangle - the primary-ray cull's - touches the tile) and lists
 // them dearest first, so the launch ends on sky.  Every tile is still rendered exactly once by exactly one workgroup: the
 // picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
-// (`cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns 2 words per entry, 8 * ceil(n/8) entries;
+// (`cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns RT_ENTRY_WORDS words per entry, 8 * ceil(n/8) entries;
 // empty on a launch that is too large for the table)
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
