@@ -786,10 +786,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // the counting variant traces them like any other (its counters are what the caller wants)
     static const bool no_sky_tiles = RT_TEST_ENV("RT_NO_SKY_TILES") != nullptr;   // A/B switch (test build)
     const bool mark_sky = L.sky_fast != 0u && !count && !no_sky_tiles;
-    // few spheres: per block and light, the spheres that can shadow a primary hit of the block at all (rt_tables.cpp); needs every
-    // lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
+    // per block and light, the spheres that can shadow a primary hit of the block at all, and the block's primary candidates
+    // (rt_tables.cpp); needs every lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
     static const bool no_shadow_masks = RT_TEST_ENV("RT_NO_SHADOW_MASKS") != nullptr;   // A/B switch (test build)
-    const bool shadow_masks = !count && !no_shadow_masks && s->cull_in_lds && (s->enclosing == ~0u || s->enclosing_flat);
+    const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
     uint32_t n_entries = 0;
     L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
                                                shadow_masks, &n_entries, &temporary);

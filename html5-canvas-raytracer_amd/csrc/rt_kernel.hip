@@ -365,7 +365,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.lrow = (e1 & 0xffffffu) + P.trow;
   P.sky = (e1 >> 31) != 0u;                            // workgroup-uniform: no sphere can show in these blocks (rt_tables.cpp) ...
   P.run = ((e1 >> 24) & 127u) + 1u;                    // ... a run of this many 32-pixel blocks, starting at tile_x
-  P.cand = e4.w;                                       // the (at most two) loop spheres the block's primary rays can meet, or 0: cull
+  P.cand = e4.w;                                       // the (at most two) loop spheres the block's primary rays can meet (count << 16 | second << 8 | first), or 0: cull
   P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
   P.valid = (P.px < L.w) && (P.trow < rows_valid);
   return P;
@@ -498,14 +498,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #if !RT_STRICT
         // A block for which the host names at most two spheres its primary rays can meet at all (word 3 of its table entry;
         // a floor block names the floor) tests those and skips the cull.
-        if (cand_host != 0u) {
-          uint32_t m = cand_host;
-          while (m) {
-            const uint32_t i = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            const rt_geom g0 = RT_LOAD(ga, i);
-            RT_ANCHORED(i, g0)
-          }
+        if (cand_host != 0u) {                           // count << 16 | second << 8 | first (loop indices, ascending)
+          { const uint32_t i = cand_host & 255u; const rt_geom g0 = RT_LOAD(ga, i); RT_ANCHORED(i, g0) }
+          if (cand_host >= (2u << 16)) { const uint32_t i = (cand_host >> 8) & 255u; const rt_geom g0 = RT_LOAD(ga, i); RT_ANCHORED(i, g0) }
         } else
 #endif
         for (uint32_t base = 0; base < NLOOP; base += 64u) {
@@ -725,7 +720,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           double li = L.light_intensity;                               // shared across lights (q2)
 #if !RT_STRICT
           [[maybe_unused]] uint32_t smask = ~0u;
-          if constexpr (!GRID && !COUNT) { if (primary_node) smask = rt_entry_shadow_masks(L); }
+          if constexpr (!COUNT) { if (primary_node) smask = rt_entry_shadow_masks(L); }
 #endif
           for (uint32_t k = 0; k < NL; k++) {
             double llen;
@@ -820,6 +815,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             const uint32_t NS = NLOOP;
 #endif
 #if !RT_STRICT
+            // Primary hits of a block whose table entry says that NO sphere can stand between the block's hit points and light k
+            // (rt_tables.cpp, shadow masks; most floor blocks): neither grid nor scan.
+            bool no_occluder = false;
+            if constexpr (!COUNT) no_occluder = primary_node && k < 2u && ((smask >> (16u * k)) & 0xffffu) == 0u;
+            if (no_occluder) {
+            } else
             if (GRID && L.shadow_grid != nullptr && li != 0.0) {
               // Many spheres: cull the scan with the light's grid.  The host cut light k's view of the scene
               // (projective coordinates x'/z', y'/z' in a frame looking from the light at the scene) into
@@ -859,13 +860,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               if (li != 0.0) {
                 uint32_t j = 0;
 #if !RT_STRICT
-                // Primary hits of a block whose table entry says that NO sphere can stand between the block's hit points and light k
-                // (rt_tables.cpp, shadow masks; most floor blocks): the scan is skipped.  Any other set takes the ordinary scan minus
-                // the pairs neither sphere of which is in the set (a loop over just the named spheres would cost the kernel its
-                // 96th register).
-                bool masked = false;
-                [[maybe_unused]] uint32_t mk = ~0u;                     // pairs of spheres neither of which can shadow are skipped as well
-                if constexpr (!GRID) { if (primary_node && k < 2u) mk = (smask >> (16u * k)) | 0xffff0000u; masked = (mk & 0xffffu) == 0u; }
+                // a non-empty set still skips the PAIRS of the scan neither sphere of which is in it (a loop over just the named
+                // spheres would cost the kernel its 96th register)
+                const bool masked = false;
+                [[maybe_unused]] uint32_t mk = ~0u;
+                if constexpr (!GRID) { if (primary_node && k < 2u) mk = (smask >> (16u * k)) | 0xffff0000u; }
                 if (!masked) {
                 if constexpr (!GRID) {
                   if (NS >= 2u) { if (mk & 3u) { const rt_geom g0 = gp_first.a, g1 = gp_first.b; RT_SHADOW_U(0u, g0) RT_SHADOW_U(1u, g1) } j = 2u; }

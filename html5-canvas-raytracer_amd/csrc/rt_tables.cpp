@@ -295,7 +295,8 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
   const double as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
                as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
   const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
-  const bool want_masks = shadow_masks && n_loop <= 16u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
+  const bool want_masks = shadow_masks && n_loop <= 256u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
+  const bool wide = n_loop > 16u;           // more than 16 loop spheres: a light's set is stored as empty (0) or not (0xffff)
   if ((mark_sky || want_masks) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
       std::isfinite(proj_d) && proj_d > 0.0) {
     if (mark_sky) touched.assign(n, 0);
@@ -350,7 +351,12 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
         const size_t at = (size_t)y * tiles_x + x;
         if (mark_sky) touched[at] = hit ? 1 : 0;
         if (!want_masks || doubt || cand.empty()) continue;
-        if (cand.size() <= 2u && n_loop <= 32u) { uint32_t cm = 0u; for (uint32_t ci : cand) cm |= 1u << balls[ci].loop; cands[at] = cm; }
+        // word 3: count << 16 | loop index of the second << 8 | loop index of the first (in index order: the tie-break of the search)
+        if (cand.size() <= 2u) {
+          uint32_t i0 = balls[cand[0]].loop, i1 = cand.size() > 1u ? balls[cand[1]].loop : 0u;
+          if (cand.size() > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
+          cands[at] = ((uint32_t)cand.size() << 16) | (i1 << 8) | i0;
+        }
         uint32_t mk[2] = {0u, 0u};
         bool ok = true;
         for (uint32_t ci : cand) {
@@ -379,7 +385,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
                 const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * w);
                 inc = !(cosang < cos12 - 1e-7) && (w - O.R <= (dist + rho) * (1.0 + 1e-7));
               }
-              if (inc) mk[k] |= 1u << O.loop;
+              if (inc) mk[k] |= wide ? 0xffffu : (1u << O.loop);
             }
           }
         }

@@ -395,6 +395,7 @@ def test_launch_table_sky_marks_are_conservative(built, scene, w, h, tiles, min_
     ("h8", 640, 360, 0.3, 0.05),
     ("cfg2", 480, 270, 0.5, 0.0),
     ("default14", 640, 360, 0.3, 0.0),             # 13 loop spheres: host logic only (its kernel variant uses the shadow grids)
+    ("lcg64_ss1", 640, 360, 0.3, 0.0),             # 63 loop spheres: sets stored as empty / not empty
     ("cfg1", 128, 128, 1.0, 0.0)])
 def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, min_empty):
     """Shadow masks of the launch table (word 2 of an entry: per light, the loop-order spheres that can shadow a PRIMARY hit of
@@ -464,7 +465,8 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                 if bi is None or bi == enclosing:
                     continue                                  # sky (flat: no lighting) or a miss
                 # word 3: the (at most two) spheres the block's primary rays can meet at all - the kernel then skips its cull
-                assert cands == 0 or (cands >> loop_of[bi]) & 1, (scene, tile_x, frow0, ix, iy, bi, hex(cands))
+                named = [cands & 255] + ([(cands >> 8) & 255] if (cands >> 16) > 1 else [])     # count << 16 | second << 8 | first
+                assert cands == 0 or loop_of[bi] in named, (scene, tile_x, frow0, ix, iy, bi, hex(cands))
                 hp = [o[k] + d[k] * best for k in range(3)]
                 for k, lt in enumerate(sc["lights"]):
                     sv = [lt[c] - hp[c] for c in range(3)]
@@ -474,7 +476,8 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                         if j == bi or j == enclosing:
                             continue
                         if hit_t(hp, sv, q) < llen:
-                            assert (smask >> (16 * k)) & (1 << loop_of[j]), (scene, tile_x, frow0, ix, iy, k, j, hex(smask))
+                            bit = (1 << loop_of[j]) if len(loop_of) <= 16 else 1      # more than 16 loop spheres: empty (0) or not (0xffff)
+                            assert (smask >> (16 * k)) & bit, (scene, tile_x, frow0, ix, iy, k, j, hex(smask))
     assert stated > 0 and empty >= min_empty * stated, (scene, stated, empty)
 
 
