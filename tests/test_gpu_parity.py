@@ -1003,13 +1003,17 @@ def test_supersample_3x3_and_4x4_tiles_scatter_and_pieces(lib, k, flags):
         assert ou.max_lsb(np.ascontiguousarray(got), want)[0] <= 1, k
 
 
-def test_the_one_intrinsic_exception_ocml_vs_libm(lib):
-    """Seed 110793 of round 1's 30 000-scene soak: ONE pixel - a depth-5 refraction tree between two large spheres - where
-    BOTH kernels give the same colour, 4 LSB away from the C and JS restatements (which agree with each other and with the
-    reference): OCML's atan2 / asin / pow differ from glibc's and V8's in the last ulp (as those two differ from each other
-    on 6-18 % of their inputs) and here that ulp lands on a discontinuity.  Intrinsic to running on another
-    maths library; pinned so that it stays ONE pixel and both kernels keep agreeing."""
-    scene, w, h = _soak_scene(110793)
+@pytest.mark.parametrize("seed,worst", [(110793, 4), (15004219, 3), (15007010, 115)])
+def test_the_intrinsic_exceptions_another_maths_library(lib, seed, worst):
+    """The one class of pixel no kernel on this hardware reproduces: the sampler's atan2 / asin (main.js:127-128, 446-447) landing
+    within an ulp of a texel or checker boundary, where OCML (strict kernel) and the product kernel's own polynomials differ in
+    the last bit from V8's fdlibm (and from glibc, which agrees with V8 in these cases: the C and JS restatements and the
+    reference itself give the same frame).  In each of these scenes - seed 110793 of round 1's soak (a depth-5 refraction tree),
+    seeds 15004219 (a texel boundary at a normal of (2/3, -1/3, -2/3)) and 15007010 (a checker column at u = 1 - 1e-16 on the
+    centre row of a 32x9 frame) of round 2's last soak, 2 scenes in 60 000 - ONE pixel differs, BOTH kernels give the same
+    colour there (profiles/r02_probe_soak_head_flips.log: identical hit point and normal, different sampled colour), and
+    everything else is within 1 LSB.  Pinned so that it stays one pixel per scene and the kernels keep agreeing."""
+    scene, w, h = _soak_scene(seed)
     blob = rt_host.flatten_scene(scene)
     want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
     a = np.frombuffer(gpu_frame(lib, blob, w, h, FAST), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
@@ -1017,7 +1021,7 @@ def test_the_one_intrinsic_exception_ocml_vs_libm(lib):
     assert np.abs(a - b).max() <= 1
     for got in (a, b):
         off = np.abs(got - want).max(axis=2) > 1
-        assert off.sum() <= 1 and np.abs(got - want).max() <= 4, (int(off.sum()), int(np.abs(got - want).max()))
+        assert off.sum() <= 1 and np.abs(got - want).max() <= worst, (int(off.sum()), int(np.abs(got - want).max()))
 
 
 def test_launch_table_cache_and_per_call_tables(lib):
