@@ -163,7 +163,7 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
 #endif
 
 // ---- atan2 / asin for the samplers (main.js:127-128, 446-447) --------------------------------------------------------
-// RT_STRICT: OCML's.  Product kernel: the same argument reductions and minimax polynomials (atan: odd polynomial of degree 39
+// RT_STRICT: fdlibm's, as the JS engines' (below).  Product kernel: OCML's argument reductions and minimax polynomials (atan: odd polynomial of degree 39
 // on [0,1] after q = min/max; asin: x + x*r*P(r), r = x^2 below 1/2 and (1-|x|)/2 above with pi/2 - 2*asin(sqrt(r))), but
 //   * every Horner step is ONE v_fma_f64 whose constant comes from an SGPR pair (hipcc otherwise writes the 64-bit literal
 //     into the v_fmac accumulator with two v_mov_b32 per step: 64 of OCML's ~230 instructions for the pair of calls),
@@ -172,8 +172,98 @@ __device__ __forceinline__ v3 unit(const v3 v, double *len_out) {
 // Accuracy: <= 2 ulp (OCML: <= 1); what the samplers make of it is a texel index / a checker parity, i.e. the same last-ulp
 // sensitivity at boundaries that OCML, glibc and V8 already have among themselves (the one listed
 // exception); the parity suite and the soaks hold the result to 1 LSB.
-#if RT_STRICT || (defined(RT_TESTING) && defined(RT_AB_OCML_TRIG))
+#if RT_STRICT
+// The strict kernel computes atan2 / asin AS THE JAVASCRIPT ENGINES DO: V8 and SpiderMonkey implement Math.atan2 / Math.asin with
+// a port of Sun's fdlibm (fixed argument reductions and coefficients, plain binary64 operations - deterministic everywhere), so
+// restating those published algorithms operation for operation (this build has no FMA contraction; `/` and sqrt are correctly
+// rounded) gives u and v the reference's own bits, where OCML's functions differ in the last ulp on a few per cent of the
+// inputs - and an ulp at a texel or checker boundary is a different pixel.  Same code as
+// oracle/fdlibm_trig.h, which the CPU tests compare with Node's Math.atan2 / Math.asin bit for bit on 0.9 M vectors.
+__device__ __forceinline__ uint32_t fd_hi(double x) { return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32); }
+__device__ __forceinline__ uint32_t fd_lo(double x) { return (uint32_t)__builtin_bit_cast(unsigned long long, x); }
+__device__ __forceinline__ double fd_atan(double x) {
+  const double hi0 = 4.63647609000806093515e-01, hi1 = 7.85398163397448278999e-01, hi2 = 9.82793723247329054082e-01, hi3 = 1.57079632679489655800e+00;
+  const double lo0 = 2.26987774529616870924e-17, lo1 = 3.06161699786838301793e-17, lo2 = 1.39033110312309984516e-17, lo3 = 6.12323399573676603587e-17;
+  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01, a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02, a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02, a10 = 1.62858201153657823623e-02;
+  const int32_t hx = (int32_t)fd_hi(x);
+  const uint32_t ix = (uint32_t)hx & 0x7fffffffu;
+  int id;
+  if (ix >= 0x44100000u) {                                            // |x| >= 2^66
+    if (ix > 0x7ff00000u || (ix == 0x7ff00000u && fd_lo(x) != 0u)) return x + x;
+    return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+  }
+  if (ix < 0x3fdc0000u) { if (ix < 0x3e200000u) return x; id = -1; }   // |x| < 0.4375 (< 2^-29: x)
+  else {
+    x = __builtin_fabs(x);
+    if (ix < 0x3ff30000u) { if (ix < 0x3fe60000u) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); } else { id = 1; x = (x - 1.0) / (x + 1.0); } }
+    else { if (ix < 0x40038000u) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); } else { id = 3; x = -1.0 / x; } }
+  }
+  const double z = x * x, w = z * z;
+  const double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+  const double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+  if (id < 0) return x - x * (s1 + s2);
+  const double ahi = id == 0 ? hi0 : (id == 1 ? hi1 : (id == 2 ? hi2 : hi3)), alo = id == 0 ? lo0 : (id == 1 ? lo1 : (id == 2 ? lo2 : lo3));
+  const double r = ahi - ((x * (s1 + s2) - alo) - x);
+  return hx < 0 ? -r : r;
+}
+__device__ __forceinline__ double fd_atan2(double y, double x) {
+  const double tiny = 1.0e-300, pi_o_4 = 7.8539816339744827900E-01, pi_o_2 = 1.5707963267948965580E+00, pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+  const int32_t hx = (int32_t)fd_hi(x), hy = (int32_t)fd_hi(y);
+  const uint32_t lx = fd_lo(x), ly = fd_lo(y), ix = (uint32_t)hx & 0x7fffffffu, iy = (uint32_t)hy & 0x7fffffffu;
+  if ((ix | ((lx | (0u - lx)) >> 31)) > 0x7ff00000u || (iy | ((ly | (0u - ly)) >> 31)) > 0x7ff00000u) return x + y;     // NaN
+  if ((((uint32_t)hx - 0x3ff00000u) | lx) == 0u) return fd_atan(y);                                                    // x == 1
+  int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                                                                          // 2 * sign(x) + sign(y)
+  if ((iy | ly) == 0u) { if (m < 2) return y; return m == 2 ? pi + tiny : -pi - tiny; }                                   // y == 0
+  if ((ix | lx) == 0u) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;                                                 // x == 0
+  if (ix == 0x7ff00000u) {
+    if (iy == 0x7ff00000u) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0 * pi_o_4 + tiny : -3.0 * pi_o_4 - tiny));
+    return m == 0 ? 0.0 : (m == 1 ? -0.0 : (m == 2 ? pi + tiny : -pi - tiny));
+  }
+  if (iy == 0x7ff00000u) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int32_t k = (int32_t)(iy - ix) >> 20;
+  double z;
+  if (k > 60) { z = pi_o_2 + 0.5 * pi_lo; m &= 1; }                                                                      // |y / x| > 2^60
+  else if (hx < 0 && k < -60) z = 0.0;                                                                                  // 0 > |y| / x > -2^-60
+  else z = fd_atan(__builtin_fabs(y / x));
+  return m == 0 ? z : (m == 1 ? -z : (m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi));
+}
+__device__ __forceinline__ double fd_asin(double x) {
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pio4_hi = 7.85398163397448278999e-01;
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+               pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
+  const double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+  const int32_t hx = (int32_t)fd_hi(x);
+  const uint32_t ix = (uint32_t)hx & 0x7fffffffu;
+  if (ix >= 0x3ff00000u) {                                            // |x| >= 1
+    if (((ix - 0x3ff00000u) | fd_lo(x)) == 0u) return x * pio2_hi + x * pio2_lo;
+    return (x - x) / (x - x);                                         // NaN
+  }
+  if (ix < 0x3fe00000u) {                                             // |x| < 0.5
+    if (ix < 0x3e400000u) return x;
+    const double t = x * x;
+    const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+    const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+    return x + x * (p / q);
+  }
+  const double w0 = 1.0 - __builtin_fabs(x);
+  double t = w0 * 0.5;
+  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+  const double s = sqrt(t);
+  if (ix >= 0x3FEF3333u) { const double w = p / q; t = pio2_hi - (2.0 * (s + s * w) - pio2_lo); }                       // |x| > 0.975
+  else {
+    const double w = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, s) & 0xffffffff00000000ull);
+    const double c = (t - w * w) / (s + w), r = p / q;
+    const double p2 = 2.0 * s * r - (pio2_lo - 2.0 * c), q2 = pio4_hi - 2.0 * w;
+    t = pio4_hi - (p2 - q2);
+  }
+  return hx > 0 ? t : -t;
+}
 // atan2(y, x) and asin(w) of one surface normal (the two halves of main.js:446-447 / :127-128)
+__device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) { *at = fd_atan2(y, x); *as = fd_asin(w); }
+#elif defined(RT_TESTING) && defined(RT_AB_OCML_TRIG)
 __device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) { *at = atan2(y, x); *as = asin(w); }
 #else
 __device__ __forceinline__ double rt_fma_k(double a, double b, double k) {     // a*b + k, k wave-uniform: v_fma_f64 v, v, v, s[..]

@@ -1003,25 +1003,24 @@ def test_supersample_3x3_and_4x4_tiles_scatter_and_pieces(lib, k, flags):
         assert ou.max_lsb(np.ascontiguousarray(got), want)[0] <= 1, k
 
 
-@pytest.mark.parametrize("seed,worst", [(110793, 4), (15004219, 3), (15007010, 115)])
-def test_the_intrinsic_exceptions_another_maths_library(lib, seed, worst):
-    """The one class of pixel no kernel on this hardware reproduces: the sampler's atan2 / asin (main.js:127-128, 446-447) landing
-    within an ulp of a texel or checker boundary, where OCML (strict kernel) and the product kernel's own polynomials differ in
-    the last bit from V8's fdlibm (and from glibc, which agrees with V8 in these cases: the C and JS restatements and the
-    reference itself give the same frame).  In each of these scenes - seed 110793 of round 1's soak (a depth-5 refraction tree),
-    seeds 15004219 (a texel boundary at a normal of (2/3, -1/3, -2/3)) and 15007010 (a checker column at u = 1 - 1e-16 on the
-    centre row of a 32x9 frame) of round 2's last soak, 2 scenes in 60 000 - ONE pixel differs, BOTH kernels give the same
-    colour there (profiles/r02_probe_soak_head_flips.log: identical hit point and normal, different sampled colour), and
-    everything else is within 1 LSB.  Pinned so that it stays one pixel per scene and the kernels keep agreeing."""
+@pytest.mark.parametrize("seed,fast_pixels,fast_worst,strict_pixels", [(110793, 1, 4, 1), (15004219, 1, 3, 0), (15007010, 0, 1, 0)])
+def test_sampler_boundaries_and_the_maths_library(lib, seed, fast_pixels, fast_worst, strict_pixels):
+    """The one class of pixel that depends on WHOSE atan2 / asin runs: the sampler's u, v (main.js:127-128, 446-447) landing within
+    an ulp of a texel or checker boundary.  With OCML's functions both kernels differed from the reference in one pixel of each
+    of these scenes (seed 110793 of round 1's soak; seeds 15004219 - a texel boundary at a normal of (2/3, -1/3, -2/3) - and
+    15007010 - a checker column at u = 1 - 1e-16 on the centre row of a 32x9 frame - of round 2's last soak, 2 scenes in 60 000;
+    profiles/r02_probe_soak_head_flips.log: identical hit point and normal, different sampled colour).  The strict kernel now
+    computes them as the JS engines do (fdlibm's algorithms, restated operation for operation and pinned against Node bit for
+    bit, tests/test_oracle.py) and reproduces the reference there; so does the product path on a centre row (rendered by the
+    strict kernel).  The product kernel's own polynomials may still differ in one pixel of such a scene."""
     scene, w, h = _soak_scene(seed)
     blob = rt_host.flatten_scene(scene)
     want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
     a = np.frombuffer(gpu_frame(lib, blob, w, h, FAST), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
     b = np.frombuffer(gpu_frame(lib, blob, w, h, STRICT), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
-    assert np.abs(a - b).max() <= 1
-    for got in (a, b):
-        off = np.abs(got - want).max(axis=2) > 1
-        assert off.sum() <= 1 and np.abs(got - want).max() <= worst, (int(off.sum()), int(np.abs(got - want).max()))
+    off_a, off_b = np.abs(a - want).max(axis=2) > 1, np.abs(b - want).max(axis=2) > 1
+    assert off_b.sum() <= strict_pixels, (int(off_b.sum()), int(np.abs(b - want).max()))
+    assert off_a.sum() <= fast_pixels and (off_a.sum() == 0 or np.abs(a - want).max() <= fast_worst), (int(off_a.sum()), int(np.abs(a - want).max()))
 
 
 def test_launch_table_cache_and_per_call_tables(lib):

@@ -140,3 +140,45 @@ def test_stars_sampler_js_and_c_restatements_agree(built, tmp_path):
     assert 5 <= len(stars) <= 120                                  # ~0.001 of the sky samples (direct and reflected)
     direct = stars[(stars[:, 0] == stars[:, 1]) & (stars[:, 1] == stars[:, 2])]
     assert len(direct) >= 3                                        # stars seen directly are grey (c, c, c)
+
+
+def _check_fdlibm_vectors(path):
+    import ctypes as C
+    lib = ou.c_oracle()
+    lib.oracle_fd_atan2.restype = C.c_double
+    lib.oracle_fd_atan2.argtypes = [C.c_double, C.c_double]
+    lib.oracle_fd_asin.restype = C.c_double
+    lib.oracle_fd_asin.argtypes = [C.c_double]
+    import struct
+    n = bad = 0
+    with open(path) as f:
+        for line in f:
+            t, a, b, r = line.split()
+            x, y = struct.unpack(">d", bytes.fromhex(a))[0], struct.unpack(">d", bytes.fromhex(b))[0]
+            got = lib.oracle_fd_atan2(x, y) if t == "2" else lib.oracle_fd_asin(x)
+            want = struct.unpack(">d", bytes.fromhex(r))[0]
+            same = struct.pack(">d", got) == bytes.fromhex(r) or (got != got and want != want)
+            bad += not same
+            n += 1
+    return n, bad
+
+
+def test_fdlibm_trig_matches_v8_fixture(built):
+    """oracle/fdlibm_trig.h (the atan2 / asin of the C restatement, and of the strict kernel) against vectors written by V8 itself
+    (node v12: oracle/fdlibm_vectors.js, committed as tests/golden/fdlibm_trig_vectors_v8.txt): bit for bit, NaNs as NaNs."""
+    import os
+    n, bad = _check_fdlibm_vectors(os.path.join(ou.ROOT, "tests", "golden", "fdlibm_trig_vectors_v8.txt"))
+    assert n > 6000 and bad == 0, (n, bad)
+
+
+def test_fdlibm_trig_matches_node(built, tmp_path):
+    """The same against a fresh, larger set from the Node that is installed here (100 000 random, tiny, huge and special inputs)."""
+    import os
+    import subprocess
+    node = ou.node_path()
+    if not node:
+        pytest.skip("node is not installed")
+    out = str(tmp_path / "vec.txt")
+    subprocess.run([node, os.path.join(ou.ROOT, "oracle", "fdlibm_vectors.js"), out, "40000"], check=True, stdout=subprocess.PIPE, timeout=300)
+    n, bad = _check_fdlibm_vectors(out)
+    assert n > 90000 and bad == 0, (n, bad)
