@@ -37,7 +37,7 @@
 //
 // The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (the product kernel)
 // and RT_STRICT=1 with -ffp-contract=off (operation for operation with the JS expression trees, IEEE
-// sqrt/div, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB on generic
+// sqrt/div, fdlibm atan2/asin, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB on generic
 // samples.  Samples whose outcome in the reference is decided by the last bit of its own arithmetic - rays
 // with an exactly-zero direction component (the centre row / column of an odd sample grid) that stay in a
 // coordinate plane through sphere centres, a light exactly on a surface - can only be reproduced by the
@@ -75,7 +75,7 @@ __device__ __forceinline__ v3 mk(double x, double y, double z) { v3 r; r.x = x; 
 __device__ __forceinline__ double dot(const v3 a, const v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // ---- math layer ----------------------------------------------------------------------------
-// RT_STRICT: IEEE-754 correctly rounded sqrt and division and OCML pow, operation for operation
+// RT_STRICT: IEEE-754 correctly rounded sqrt and division, fdlibm's atan2 / asin and OCML pow, operation for operation
 // with the JS expression trees.  Otherwise (product kernel): the hardware estimates v_rsq_f64 /
 // v_rcp_f64 refined by Newton steps in FMA arithmetic (<= ~1 ulp, no denormal pre-scaling, no
 // div_scale/div_fixup), reciprocal-multiplies for divisions by constants, and integer powers by

@@ -6,7 +6,7 @@ binary64; the only admissible differences are exact-.5 rounding ties moved by an
 binary64 kernel is pinned here too: samples whose outcome in the reference hinges on an exact coincidence (centre row /
 column of an odd sample grid, a light on a surface) are rendered by the operation-for-operation kernel
 (test_soak_seeds_on_exact_coincidences, test_centre_row_and_column_come_from_the_strict_kernel), and the one known
-pixel where OCML and libm part by an ulp on a discontinuity is listed (test_the_one_intrinsic_exception_ocml_vs_libm).
+class of pixel that depends on whose atan2 / asin runs at a sampler boundary is listed (test_sampler_boundaries_and_the_maths_library).
 """
 import ctypes as C
 import math
