@@ -128,7 +128,7 @@ struct rt_scene_dev {
   std::vector<rt_sphere> host_objects;   // the scene's sphere records (scene order), for the launch table's sky marking
   std::vector<rt_geom> host_cull;
   std::vector<uint32_t> tile_weight;
-  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks; uint32_t n_entries; uint32_t *d_order; };
+  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t n_entries; uint32_t *d_order; };
   std::vector<order_entry> orders;
   std::mutex order_mu;
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
@@ -491,17 +491,17 @@ extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h,
 
 namespace {
 const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, uint32_t *n_entries, bool *temporary) {
+                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t *n_entries, bool *temporary) {
   *temporary = false;
   std::lock_guard<std::mutex> lk(s->order_mu);
   for (const rt_scene_dev::order_entry &e : s->orders)
     if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
-        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks) {
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates) {
       *n_entries = e.n_entries;
       return e.d_order;
     }
   const std::vector<uint32_t> table = build_launch_table(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile,
-                                                         proj_w, proj_h, proj_d, ranked, mark_sky, s->enclosing, shadow_masks, s->lights, n_entries);
+                                                         proj_w, proj_h, proj_d, ranked, mark_sky, s->enclosing, shadow_masks, name_candidates, s->lights, n_entries);
   if (table.empty()) { fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile); return nullptr; }
   uint32_t *d = nullptr;
   hipError_t e = hipMalloc((void **)&d, table.size() * 4u);
@@ -511,7 +511,7 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
   // been rendered with 64 different (frame size, tile set) pairs gets per-call tables from then on, freed by the caller once
   // its launches have drained.
   if (s->orders.size() >= 64u) { *temporary = true; return d; }
-  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, mark_sky, shadow_masks, *n_entries, d});
+  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, mark_sky, shadow_masks, name_candidates, *n_entries, d});
   return d;
 }
 
@@ -543,7 +543,7 @@ extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w,
   const uint32_t sky_sphere = enclosing_sphere(hd, ob, lights);
   uint32_t n_entries = 0;
   const std::vector<uint32_t> table = build_launch_table(hd, ob, cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, sky_sphere,
-                                                         (ranked & 4) != 0, lights, &n_entries);
+                                                         (ranked & 4) != 0, (ranked & 4) != 0, lights, &n_entries);
   if (table.empty()) return fail(RT_ERR_INVALID, "a launch of this size is beyond the launch table");
   *n_workgroups = n_entries;
   if (out_entries) memcpy(out_entries, table.data(), table.size() * sizeof(uint32_t));
@@ -790,9 +790,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // (rt_tables.cpp); needs every lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
     static const bool no_shadow_masks = RT_TEST_ENV("RT_NO_SHADOW_MASKS") != nullptr;   // A/B switch (test build)
     const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
+    const bool name_candidates = !count && !no_shadow_masks;
     uint32_t n_entries = 0;
     L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
-                                               shadow_masks, &n_entries, &temporary);
+                                               shadow_masks, name_candidates, &n_entries, &temporary);
     if (!L.order) return RT_ERR_DEVICE;
     if (temporary) { temp_table.p = (void *)L.order; temp_table.st = stream; }
     L.order_n8 = (n_entries + 7u) / 8u;

@@ -238,7 +238,7 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
                                          const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, const double lights[][3], uint32_t *n_entries) {
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
   if (n_entries) *n_entries = 0;
@@ -296,11 +296,13 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
                as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
   const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
   const bool want_masks = shadow_masks && n_loop <= 256u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
+  const bool want_cands = name_candidates && n_loop <= 256u;                 // (no light needed, and any enclosing sphere: it is outside the loops)
   const bool wide = n_loop > 16u;           // more than 16 loop spheres: a light's set is stored as empty (0) or not (0xffff)
-  if ((mark_sky || want_masks) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
+  if ((mark_sky || want_masks || want_cands) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
       std::isfinite(proj_d) && proj_d > 0.0) {
     if (mark_sky) touched.assign(n, 0);
-    if (want_masks) { smask.assign(n, 0xffffffffu); cands.assign(n, 0u); }
+    if (want_masks) smask.assign(n, 0xffffffffu);
+    if (want_cands) cands.assign(n, 0u);
     struct ball { double c[3], o[3], len, R, k, sin_b, cos_b; uint32_t loop; bool everywhere; };
     std::vector<ball> balls;
     for (uint32_t j = 0; j < hd->n_objects; j++) {
@@ -350,13 +352,14 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
         }
         const size_t at = (size_t)y * tiles_x + x;
         if (mark_sky) touched[at] = hit ? 1 : 0;
-        if (!want_masks || doubt || cand.empty()) continue;
+        if (doubt || cand.empty()) continue;
         // word 3: count << 16 | loop index of the second << 8 | loop index of the first (in index order: the tie-break of the search)
-        if (cand.size() <= 2u) {
+        if (want_cands && cand.size() <= 2u) {
           uint32_t i0 = balls[cand[0]].loop, i1 = cand.size() > 1u ? balls[cand[1]].loop : 0u;
           if (cand.size() > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
           cands[at] = ((uint32_t)cand.size() << 16) | (i1 << 8) | i0;
         }
+        if (!want_masks) continue;
         uint32_t mk[2] = {0u, 0u};
         bool ok = true;
         for (uint32_t ci : cand) {

@@ -30,12 +30,13 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 // sphere other than `sky_sphere` (scene order; ~0u: none) - the kernel stores the background constant there and skips everything else;
 // consecutive marked blocks of a row block share ONE entry (run length - 1 in bits 24..30); `ob` = the scene's sphere records
 // (host copy, scene order); *n_entries = the number of entries = workgroups of the launch;
-// shadow_masks (few spheres, at most two lights): word 2 of an entry = per light the 16-bit set of loop-order spheres that can
+// name_candidates: word 3 = the (at most two) loop spheres the block's primary rays can meet (count << 16 | second << 8 | first),
+// or 0.  shadow_masks (at most two lights): word 2 of an entry = per light the 16-bit set of loop-order spheres that can
 // shadow a PRIMARY hit of the block, 0xffffffff = scan everything
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
                                          const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, const double lights[][3], uint32_t *n_entries);
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries);
 constexpr uint32_t RT_ENTRY_WORDS = 4u;      // {tile_x | rows_valid << 11 | first frame row << 15, band row | run << 24 | sky << 31, shadow masks, reserved}
 
 }  // namespace rt_tables

@@ -396,7 +396,8 @@ def test_launch_table_sky_marks_are_conservative(built, scene, w, h, tiles, min_
     ("cfg2", 480, 270, 0.5, 0.0),
     ("default14", 640, 360, 0.3, 0.0),             # 13 loop spheres: host logic only (its kernel variant uses the shadow grids)
     ("lcg64_ss1", 640, 360, 0.3, 0.0),             # 63 loop spheres: sets stored as empty / not empty
-    ("cfg1", 128, 128, 1.0, 0.0)])
+    ("cfg1", 128, 128, 1.0, 0.0),
+    ("nolights:h8", 640, 360, 0.3, 0.0)])           # NO light: candidates are named, shadow sets are not
 def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, min_empty):
     """Shadow masks of the launch table (word 2 of an entry: per light, the loop-order spheres that can shadow a PRIMARY hit of
     the block at all; the kernel skips the scan of a light whose set is empty): for sampled blocks every sample's primary hit
@@ -406,7 +407,11 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
     import math
     import random
     lib = rt_host.load_library()
-    sc = rt_host.load_scene(scene)
+    if scene.startswith("nolights:"):
+        sc = rt_host.load_scene(scene[9:])
+        sc["lights"] = []
+    else:
+        sc = rt_host.load_scene(scene)
     blob = rt_host.flatten_scene(sc)
     ss = sc.get("supersample", 1)
     assert ss == 1
@@ -441,12 +446,13 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
         t = t1 if t0 < eps else t0
         return math.inf if t < eps else t
     rng = random.Random(11)
-    stated = empty = 0
+    stated = empty = named_blocks = 0
     for tile_x, valid, frow0, _lrow, smask, cands in entries:
-        if not valid or smask == 0xffffffff:
+        if not valid or (smask == 0xffffffff and cands == 0):
             continue
-        stated += 1
+        stated += smask != 0xffffffff
         empty += (smask == 0)
+        named_blocks += cands != 0
         if rng.random() > sample:
             continue
         for iy in sorted({0, valid - 1, rng.randrange(valid)}):
@@ -468,7 +474,7 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                 named = [cands & 255] + ([(cands >> 8) & 255] if (cands >> 16) > 1 else [])     # count << 16 | second << 8 | first
                 assert cands == 0 or loop_of[bi] in named, (scene, tile_x, frow0, ix, iy, bi, hex(cands))
                 hp = [o[k] + d[k] * best for k in range(3)]
-                for k, lt in enumerate(sc["lights"]):
+                for k, lt in enumerate(sc["lights"] if smask != 0xffffffff else []):
                     sv = [lt[c] - hp[c] for c in range(3)]
                     llen = math.sqrt(sum(c * c for c in sv))
                     sv = [c / llen for c in sv]
@@ -478,7 +484,7 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                         if hit_t(hp, sv, q) < llen:
                             bit = (1 << loop_of[j]) if len(loop_of) <= 16 else 1      # more than 16 loop spheres: empty (0) or not (0xffff)
                             assert (smask >> (16 * k)) & bit, (scene, tile_x, frow0, ix, iy, k, j, hex(smask))
-    assert stated > 0 and empty >= min_empty * stated, (scene, stated, empty)
+    assert named_blocks > 0 and (stated > 0 or not sc["lights"]) and empty >= min_empty * stated, (scene, stated, empty, named_blocks)
 
 
 @pytest.mark.parametrize("scene,w,h,tiles", [
