@@ -368,7 +368,9 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
           const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
           const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
           const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), sqrt(fmax(B.k, 0.0)));
-          if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo)) { ok = false; break; }
+          // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
+          // to a sphere gets no statement)
+          if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(hd->epsilon))) { ok = false; break; }
           const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
           if (!(t2 >= t1) || !(t1 >= 0.0) || !std::isfinite(t2)) { ok = false; break; }
           const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
