@@ -311,7 +311,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
       for (int c = 0; c < 3; c++) { B.o[c] = ob[j].origin[c]; B.c[c] = ob[j].origin[c] - hd->cam_origin[c]; }
       B.len = sqrt(B.c[0] * B.c[0] + B.c[1] * B.c[1] + B.c[2] * B.c[2]);
       B.R = sqrt(ob[j].r2) * (1.0 + 1e-7);
-      B.k = B.len * B.len - B.R * B.R;
+      B.k = B.len * B.len - ob[j].r2;                    // with the TRUE radius: the tangent length sqrt(k) bounds the hit distances from above
       B.loop = (sky_sphere != ~0u && j > sky_sphere) ? j - 1u : j;       // index in the product kernel's loop order (enclosing sphere last)
       B.everywhere = !(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7));      // camera inside / on / unknown
       B.sin_b = B.cos_b = 0.0;
