@@ -382,13 +382,13 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
               if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
               const ball &O = balls[j];
               const double W[3] = {O.o[0] - lights[k][0], O.o[1] - lights[k][1], O.o[2] - lights[k][2]};
-              const double w = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+              const double wl = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);             // light to the occluder's centre
               bool inc;
-              if (!(w > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !std::isfinite(w) || !std::isfinite(dist)) inc = true;     // light inside the occluder or the patch
+              if (!(wl > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !std::isfinite(wl) || !std::isfinite(dist)) inc = true;     // light inside the occluder or the patch
               else {
-                const double s1 = rho / dist, s2 = O.R / w, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
-                const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * w);
-                inc = !(cosang < cos12 - 1e-7) && (w - O.R <= (dist + rho) * (1.0 + 1e-7));
+                const double s1 = rho / dist, s2 = O.R / wl, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
+                const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * wl);
+                inc = !(cosang < cos12 - 1e-7) && (wl - O.R <= (dist + rho) * (1.0 + 1e-7));
               }
               if (inc) mk[k] |= wide ? 0xffffu : (1u << O.loop);
             }
