@@ -25,6 +25,7 @@
 
 extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, hipStream_t);
+extern "C" int rt_launch_retrace(const rt_launch *, int, int, unsigned, hipStream_t);
 
 using namespace rt_tables;   // the host-built tables (pure host logic, rt_tables.cpp)
 
@@ -130,8 +131,18 @@ struct rt_scene_dev {
   std::vector<uint32_t> tile_weight;
   struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t n_entries; uint32_t *d_order; };
   std::vector<order_entry> orders;
+  // Marked samples (rt_device.h, rt_kernel.hip: rt_retrace).  One state per (launch table, stream): the device list the product
+  // launch appends to and rt_retrace reads, which of its two counters the next launch uses, and a pinned host word in which
+  // rt_retrace publishes how many samples a frame of this scene, camera, size and tile set marks - the same every time, so once it
+  // says "none" (and the sample grid has no odd centre) the second launch is skipped.  Launches that share a state share a
+  // stream, i.e. they are ordered; mark_mu makes a launch pair one step for the threads of this process.
+  struct mark_state { uint32_t order_index; hipStream_t stream; uint32_t *d_marks; volatile uint32_t *h_known; uint32_t slot; };
+  std::vector<mark_state> mark_states;
+  uint32_t *h_known_pool = nullptr;      // RT_MARK_STATES pinned words
+  std::mutex mark_mu;
   std::mutex order_mu;
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
+  double flag_tol;               // RT_FLAG_T1 x the largest sampler frequency of the scene (texture width / height, checker frequencies): rt_device.h
 };
 
 // ------------------------------------------------------------------------------------ lifetime
@@ -267,8 +278,9 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   //   * a light exactly ON a sphere's surface (the reference's own `t < light_len`, main.js:297, then compares two numbers
   //     that are equal up to rounding: a coin flip that only the reference's own arithmetic reproduces);
   //   * a sphere with r2 <= 0 or not finite (no 1/r);
+  //   * a sphere-checker whose frequencies are negative, NaN or >= 2^31 (below);
   //   * a camera whose axis sums (main.js:187-191, quirk q1) have an exactly zero component: EVERY primary ray then lies in
-  //     a coordinate plane through the camera (see the centre row / column fix-up in render_batch_impl).
+  //     a coordinate plane through the camera (rt_kernel.hip marks the centre row / column of an odd sample grid for the same reason).
   s->needs_strict = false;
   for (int c = 0; c < 3; c++) if (hd->cam_axis_x[c] + hd->cam_axis_y[c] + hd->cam_axis_z[c] == 0.0) s->needs_strict = true;
   for (uint32_t i = 0; i < hd->n_objects; i++) {
@@ -280,6 +292,24 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     }
   }
 
+  // the boundary test of the product kernel's samplers (rt_device.h: RT_FLAG_T1): a coordinate is u * frequency
+  {
+    double fmaxq = 1.0;
+    const rt_texture_desc *td = (const rt_texture_desc *)(base + hd->textures_offset);
+    for (uint32_t i = 0; i < hd->n_objects; i++) {
+      if (ob[i].sampler_kind != RT_SAMPLER_TEXTURE && ob[i].sampler_kind != RT_SAMPLER_CHECKER) continue;
+      if (ob[i].sampler_kind == RT_SAMPLER_TEXTURE) fmaxq = fmax(fmaxq, (double)(td[ob[i].texture].width > td[ob[i].texture].height ? td[ob[i].texture].width : td[ob[i].texture].height));
+      if (ob[i].sampler_kind == RT_SAMPLER_CHECKER) {
+        const double f0 = ob[i].checker_freq[0], f1 = ob[i].checker_freq[1];
+        if (fabs(f0) > fmaxq) fmaxq = fabs(f0);                       // (NaN frequencies: every sample of such a sphere is NaN, and marked)
+        if (fabs(f1) > fmaxq) fmaxq = fabs(f1);
+        // the product kernel takes ToInt32(u * f) & 1 (main.js:129-130) from a fixed-point sum that holds it for products in [0, 2^31):
+        // other frequencies (negative, huge, NaN) make the scene a strict-kernel scene
+        if (!(f0 >= 0.0 && f0 < 2147483648.0 && f1 >= 0.0 && f1 < 2147483648.0)) s->needs_strict = true;
+      }
+    }
+    s->flag_tol = RT_FLAG_T1 * fmaxq;
+  }
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
   rt_texture_desc descs[RT_MAX_TEXTURES];
@@ -430,6 +460,8 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
   if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
   for (const rt_scene_dev::order_entry &e : s->orders) (void)hipFree(e.d_order);
+  for (const rt_scene_dev::mark_state &m : s->mark_states) (void)hipFree(m.d_marks);
+  if (s->h_known_pool) (void)hipHostFree(s->h_known_pool);
   delete s;
 }
 
@@ -491,15 +523,20 @@ extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h,
 
 namespace {
 const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t *n_entries, bool *temporary) {
+                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t *n_entries, bool *temporary,
+                           uint32_t *order_index) {
   *temporary = false;
+  *order_index = ~0u;
   std::lock_guard<std::mutex> lk(s->order_mu);
-  for (const rt_scene_dev::order_entry &e : s->orders)
+  for (size_t i = 0; i < s->orders.size(); i++) {
+    const rt_scene_dev::order_entry &e = s->orders[i];
     if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
         e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates) {
       *n_entries = e.n_entries;
+      *order_index = (uint32_t)i;
       return e.d_order;
     }
+  }
   const std::vector<uint32_t> table = build_launch_table(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile,
                                                          proj_w, proj_h, proj_d, ranked, mark_sky, s->enclosing, shadow_masks, name_candidates, s->lights, n_entries);
   if (table.empty()) { fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile); return nullptr; }
@@ -512,6 +549,7 @@ const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss,
   // its launches have drained.
   if (s->orders.size() >= 64u) { *temporary = true; return d; }
   s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, mark_sky, shadow_masks, name_candidates, *n_entries, d});
+  *order_index = (uint32_t)(s->orders.size() - 1u);
   return d;
 }
 
@@ -734,6 +772,15 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
   bind_kernel(L, strict_main);
+  // the boundary test of the product kernel's samplers (rt_device.h)
+  L.flag_tol = s->flag_tol;
+  bool test_marks = false;               // test build: a switch that changes what is marked or re-traced - nothing is cached then
+#ifdef RT_TESTING
+  if (const char *fs = getenv("RT_FLAG_SCALE")) { L.flag_tol *= atof(fs); test_marks = true; }        // a wider boundary band, to exercise the second launch
+  if (getenv("RT_MARK_ALL") || getenv("RT_EXACT_ALL") || no_fixup) test_marks = true;
+#endif
+  L.mark_flags = (RT_TEST_ENV("RT_MARK_ALL") ? RT_MARK_ALL : 0u) | (no_fixup ? RT_MARK_NEVER : 0u);
+  L.marks_cap = RT_MARKS_CAP;
   L.textures = s->d_texdesc;
   L.texel_base = db;
   L.out = (uint32_t *)d_out;
@@ -762,7 +809,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
   L.ray_bias[0] = 0.5 - L.proj_w; L.ray_bias[1] = L.proj_h - 0.5; L.ray_bias[2] = L.cam_axis_sum[2] * L.proj_d;
-  L.win_w = L.win_h = ~0u;                                       // the whole frame
   if (count) HIP_TRY(hipMemsetAsync(D.d_counters, 0, 3 * sizeof(unsigned long long), stream));
 #ifdef RT_TESTING
   L.probe = g_probe.d_buf; L.probe_x = g_probe.x; L.probe_y = g_probe.y;
@@ -779,7 +825,9 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   struct table_guard {                                   // a per-call launch table is released on every way out, after the stream has drained
     void *p = nullptr; hipStream_t st = nullptr;
     ~table_guard() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
-  } temp_table;
+  } temp_table, temp_marks;
+  rt_scene_dev::mark_state temp_state = {~0u, nullptr, nullptr, nullptr, 0u};
+  uint32_t order_index = ~0u;
   if (!strict_main) {
     bool temporary = false;
     // workgroups no sphere can show in are marked in the table and store the background constant without tracing (rt_tables.cpp);
@@ -793,44 +841,70 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     const bool name_candidates = !count && !no_shadow_masks;
     uint32_t n_entries = 0;
     L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
-                                               shadow_masks, name_candidates, &n_entries, &temporary);
+                                               shadow_masks, name_candidates, &n_entries, &temporary, &order_index);
     if (!L.order) return RT_ERR_DEVICE;
     if (temporary) { temp_table.p = (void *)L.order; temp_table.st = stream; }
     L.order_n8 = (n_entries + 7u) / 8u;
     L.grid_x = n_entries; L.grid_y = 1u;               // one workgroup per table entry (runs of sky blocks share one)
   }
-  int err = (strict_main ? rt_launch_trace_strict : rt_launch_trace_fast)(&L, s->refract, count, ss2, lds_for(strict_main), stream);
-  // Centre row / centre column of a sample grid with an ODD number of rows / columns.  The primary rays there have a direction
-  // component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they spawn that stays in that
-  // plane - live in a coordinate plane through the camera, and a sphere centred on that plane (the reference's own scene has
-  // several) is met with a normal component of exactly 0: u or v lands exactly ON a texel / checker boundary (main.js:127-130,
-  // 344-347), and on which side the reference falls is decided by whether ITS OWN rounding noise (e.g. main.js:257-259 at
-  // refract_index 1, where q is 0 or 1e-16 depending on the last bit of cosi) pushed the ray off the plane.  No arithmetic
-  // but the reference's own reproduces such coin flips, so these samples - one row and one 8-pixel column group of the frame
-  // at most - are rendered by the strict kernel, on top of the product kernel's frame.
-  if (err == 0 && !strict_main && !no_fixup) {
-    const uint32_t ssf = ss2 ? 2u : 1u;
-    const bool odd_rows = ((h * ssf) & 1u) != 0, odd_cols = ((w * ssf) & 1u) != 0;
-    rt_launch F = L;
-    F.order = nullptr;
-    bind_kernel(F, true);
-    F.counters = D.d_counters;
-    if (odd_rows) {
-      const uint32_t crow = (h - 1u) / 2u, tc = crow / tiles->tile_rows;       // the output row that holds the centre sample row
-      if (tc >= tiles->tile_first && (tc - tiles->tile_first) % tiles->tile_stride == 0 && (tc - tiles->tile_first) / tiles->tile_stride < tiles->n_tiles) {
-        const uint32_t ti = (tc - tiles->tile_first) / tiles->tile_stride;
-        F.grid_x = 0u; F.bx0 = 0u;
-        F.grid_y = 1u; F.by0 = ti * L.rb_per_tile + (crow - tc * tiles->tile_rows) / rows_per_wg;
-        F.win_x0 = 0u; F.win_w = ~0u; F.win_y0 = crow; F.win_h = 1u;
-        err = rt_launch_trace_strict(&F, s->refract, 0, ss2, lds_for(true), stream);
+  int err = 0;
+  uint32_t marks_read_slot = 0;
+  const uint32_t *marks_read = nullptr;                 // stats: where this launch's mark count can be read afterwards
+  uint64_t centre_items = 0;
+  bool retraced_all = false;
+  if (strict_main) err = rt_launch_trace_strict(&L, s->refract, count, ss2, lds_for(true), stream);
+  else {
+    // ---- the product launch and, unless this frame is KNOWN to have nothing for it, the list-driven strict launch behind it ----
+    std::lock_guard<std::mutex> mk(s->mark_mu);
+    rt_scene_dev::mark_state *ms = nullptr;
+    if (order_index != ~0u) for (rt_scene_dev::mark_state &m : s->mark_states) if (m.order_index == order_index && m.stream == stream) ms = &m;
+    if (!ms) {
+      // first launch of this (table, stream) pair - or a per-call table: a list of its own, released with the table
+      constexpr size_t RT_MARK_STATES = 256;
+      const size_t bytes = 16u + (size_t)RT_MARKS_CAP * 8u;
+      uint32_t *d = nullptr;
+      hipError_t e = hipMalloc((void **)&d, bytes);
+      if (e == hipSuccess) e = hipMemsetAsync(d, 0, 16u, stream);
+      if (e != hipSuccess) { if (d) (void)hipFree(d); return fail(RT_ERR_DEVICE, "mark list: %s", hipGetErrorString(e)); }
+      if (order_index == ~0u) { temp_marks.p = d; temp_marks.st = stream; temp_state = rt_scene_dev::mark_state{~0u, stream, d, nullptr, 0u}; ms = &temp_state; }
+      else {
+        if (!s->h_known_pool && hipHostMalloc((void **)&s->h_known_pool, RT_MARK_STATES * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) memset(s->h_known_pool, 0, RT_MARK_STATES * sizeof(uint32_t));
+        else if (!s->h_known_pool) (void)hipGetLastError();
+        volatile uint32_t *known = (s->h_known_pool && s->mark_states.size() < RT_MARK_STATES) ? s->h_known_pool + s->mark_states.size() : nullptr;
+        s->mark_states.push_back(rt_scene_dev::mark_state{order_index, stream, d, known, 0u});
+        ms = &s->mark_states.back();
       }
     }
-    if (err == 0 && odd_cols) {
-      const uint32_t ccol = (w - 1u) / 2u;
-      F.grid_x = 1u; F.bx0 = ccol / RT_TILE_W;
-      F.grid_y = 0u; F.by0 = 0u;
-      F.win_x0 = ccol & ~7u; F.win_w = 8u; F.win_y0 = 0u; F.win_h = ~0u;     // a whole 8-pixel group: the unit of the RGB24 store
-      err = rt_launch_trace_strict(&F, s->refract, 0, ss2, lds_for(true), stream);
+    L.marks = ms->d_marks; L.marks_slot = ms->slot;
+    err = rt_launch_trace_fast(&L, s->refract, count, ss2, lds_for(false), stream);
+    // Centre row / centre column of a sample grid with an ODD number of rows / columns (supersample 2 makes it even).  The primary
+    // rays there have a direction component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they
+    // spawn that stays in that plane - live in a coordinate plane through the camera, and a sphere centred on that plane (the
+    // reference's own scene has several) is met with a normal component of exactly 0: u or v lands exactly ON a texel / checker
+    // boundary (main.js:127-130, 344-347), and on which side the reference falls is decided by whether ITS OWN rounding noise
+    // (e.g. main.js:257-259 at refract_index 1, where q is 0 or 1e-16 depending on the last bit of cosi) pushed the ray off the
+    // plane.  No arithmetic but the reference's own reproduces such coin flips: rt_retrace traces those samples too.
+    rt_launch F = L;
+    F.order = nullptr; F.grid_x = F.grid_y = 0u;
+    F.centre_row = F.centre_col = ~0u;
+    if (!ss2 && (h & 1u)) {
+      const uint32_t crow = (h - 1u) / 2u, tc = crow / tiles->tile_rows;
+      if (tc >= tiles->tile_first && (tc - tiles->tile_first) % tiles->tile_stride == 0 && (tc - tiles->tile_first) / tiles->tile_stride < tiles->n_tiles) { F.centre_row = crow; centre_items += (uint64_t)w * n_frames; }
+    }
+    if (!ss2 && (w & 1u)) { F.centre_col = (w - 1u) / 2u; centre_items += (uint64_t)tiles->n_tiles * tiles->tile_rows * n_frames; }
+    const bool retrace_all = RT_TEST_ENV("RT_EXACT_ALL") != nullptr && !no_fixup;
+    const uint32_t known = (ms->h_known && !test_marks) ? *ms->h_known : 0u;        // 0: not known (yet); else the frame's mark count + 1
+    const bool need = !no_fixup && (known != 1u || centre_items != 0 || retrace_all);
+    if (err == 0 && need) {
+      bind_kernel(F, true);                             // the scene in its own order, every sphere in the loops, the reference's own miss colour
+      F.marks_known = test_marks ? nullptr : (uint32_t *)ms->h_known;
+      F.retrace_all = retrace_all ? 1u : 0u;
+      retraced_all = retrace_all;
+      uint64_t n_wg = (centre_items + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;
+      if (retrace_all) n_wg = ((uint64_t)tiles->n_tiles * tiles->tile_rows * w * n_frames + RT_WG_THREADS - 1) / RT_WG_THREADS;
+      err = rt_launch_retrace(&F, s->refract, ss2, (unsigned)(n_wg < 8192u ? n_wg : 8192u), stream);
+      marks_read = ms->d_marks; marks_read_slot = ms->slot;
+      ms->slot ^= 1u;                                   // rt_retrace cleared the other counter: the next launch's
     }
   }
   if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
@@ -851,6 +925,12 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       unsigned long long c[3];
       HIP_TRY(hipMemcpy(c, D.d_counters, sizeof c, hipMemcpyDeviceToHost));
       stats->rays = c[0]; stats->shadow_rays = c[1]; stats->sphere_tests = c[2];
+    }
+    // samples the second launch traced again: the marked ones (read back from the list's counter) and the odd grid's centre lines
+    if (marks_read) {
+      uint32_t n_marked = 0;
+      HIP_TRY(hipMemcpy(&n_marked, marks_read + marks_read_slot, sizeof n_marked, hipMemcpyDeviceToHost));
+      stats->exact_samples = (n_marked > RT_MARKS_CAP || retraced_all) ? stats->pixels : n_marked + centre_items;   // (list overflow / test build: every pixel of the call)
     }
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }

@@ -87,16 +87,37 @@ struct rt_launch {
   // dearest first, so that a launch ends on cheap tiles.  The strict kernel runs on the plain 2-D grid and ignores it.
   const uint32_t *order;
   uint32_t order_n8;                 // ceil(workgroups / 8): entry of workgroup b sits at (b % 8) * order_n8 + b / 8 (one contiguous part per XCD)
-  // Fix-up launches (strict kernel only, rt_api.hip render_batch_impl): the grid starts at workgroup (bx0, by0) and only the
-  // pixels of the window [win_x0, win_x0 + win_w) x [win_y0, win_y0 + win_h) (frame coordinates) are stored.
-  uint32_t bx0, by0, win_x0, win_w, win_y0, win_h;
-  uint32_t grid_x, grid_y;           // host side only: the fix-up launch's grid (0 = the whole grid)
+  uint32_t grid_x, grid_y;           // host side only: the product launch's flat grid (one workgroup per table entry; 0 = the plain 2-D grid)
+  // Samples on exact coincidences.  A sample whose outcome in the reference hinges on the last bit of the reference's own
+  // arithmetic is traced a second time with the reference's own operation sequence by the strict build's list-driven kernel
+  // (rt_kernel.hip: rt_retrace; rt_api.hip launches it after the product launch): the samples the product kernel MARKED - a sampler
+  // coordinate within rounding of a texel / checker boundary (main.js:129-130, 344-347) - and the centre row / column of an odd
+  // sample grid (a primary ray with an exactly-zero component, main.js:186).
+  uint32_t *marks;                   // words 0, 1: the mark counters of alternate launches; words 4...: entries of 8 bytes (sample x | y << 20 | frame << 40)
+  uint32_t marks_slot;               // the counter THIS launch (and its rt_retrace) uses; rt_retrace clears the other
+  uint32_t marks_cap;                // entries the list holds; beyond it only the count grows and rt_retrace traces every sample
+  double flag_tol;                   // tolerance of the boundary test: RT_FLAG_T1 x the largest sampler frequency of the scene
+  uint32_t mark_flags;               // RT_MARK_* (below)
+  // rt_retrace only
+  uint32_t *marks_known;             // pinned host word that receives count + 1, or NULL
+  uint32_t centre_row, centre_col;   // frame row / column of the odd sample grid's centre within this call's tiles, or ~0u
+  uint32_t retrace_all;              // test build (RT_EXACT_ALL): every sample of the call
 #ifdef RT_TESTING
   // test build only (librt_hip_test.so): per-node records of ONE sample's ray tree, for parity debugging
   double *probe;                     // RT_PROBE_NODES records of RT_PROBE_WORDS doubles, or NULL
   uint32_t probe_x, probe_y;         // the sample, in sample-grid coordinates
 #endif
 };
+
+// Boundary test of the samplers (product kernels): a sampler coordinate x = u * frequency is "on a boundary" when it lies within
+// RT_FLAG_T1 * (the scene's largest frequency) of an integer: 1e-9 for the reference's checker (5000 per unit u, main.js:129), three
+// to four orders of magnitude above what the product kernel's u, v differ from the reference's by at a primary or a shallow bounce
+// hit (u to ~1e-16, a coordinate to ~1e-12), and rare enough (4e-9 per sampled hit) that a 3840x2160 frame has a marked sample once
+// in ~50 frames.  Marked samples are traced again by rt_retrace.  RT_MARKS_CAP: entries of a launch's mark list.
+#define RT_FLAG_T1 2e-13
+#define RT_MARKS_CAP 8192u
+#define RT_MARK_ALL 4u               /* test build (RT_MARK_ALL): every hit with a texture / checker sampler is marked */
+#define RT_MARK_NEVER 8u             /* test build (RT_NO_FIXUP): nothing is marked - the product kernel's own pixels */
 
 #define RT_PROBE_WORDS 24u
 #define RT_PROBE_NODES 64u

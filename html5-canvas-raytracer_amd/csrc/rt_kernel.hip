@@ -35,15 +35,17 @@
 //     a hit is pinned inside its branch, so a wave whose 64 rays all miss a sphere pays 4 FP64 operations
 //     and one compare for it.
 //
-// The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (the product kernel)
+// The file is compiled twice (csrc/Makefile): RT_STRICT=0 with FMA contraction (the product kernels)
 // and RT_STRICT=1 with -ffp-contract=off (operation for operation with the JS expression trees, IEEE
 // sqrt/div, fdlibm atan2/asin, OCML pow, explicit recursion stack; RT_FLAG_STRICT_FP).  Both are held to <= 1 LSB on generic
-// samples.  Samples whose outcome in the reference is decided by the last bit of its own arithmetic - rays
-// with an exactly-zero direction component (the centre row / column of an odd sample grid) that stay in a
-// coordinate plane through sphere centres, a light exactly on a surface - can only be reproduced by the
-// reference's own operation sequence: the library renders those with the strict kernel (rt_api.hip:
-// render_batch_impl's fix-up launches, rt_scene_dev::needs_strict), which is why the strict build takes a
-// window and a grid offset.
+// samples.  Samples whose outcome in the reference is decided by the last bit of its own arithmetic - a sampler coordinate
+// within rounding of a texel / checker boundary, rays with an exactly-zero direction component (the centre row / column of an
+// odd sample grid) that stay in a coordinate plane through sphere centres - can only be reproduced by the reference's own
+// operation sequence.  The product kernels MARK the former while tracing (a list in HBM); the strict build has a second,
+// list-driven kernel (rt_retrace) that traces the marked samples and the centre row / column again and stores over them
+// (rt_api.hip: render_batch_impl launches it unless it KNOWS that a frame of this scene, camera, size and tile set has neither).
+// Scenes that sit on a coincidence as a whole (a light exactly on a surface, a camera with a zero axis sum:
+// rt_scene_dev::needs_strict) take the strict kernels throughout.
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -272,27 +274,32 @@ __device__ __forceinline__ double rt_fma_k(double a, double b, double k) {     /
   return r;
 }
 typedef const double __attribute__((address_space(4))) *rt_trig_kptr;
-typedef double __attribute__((ext_vector_type(8))) rt_d8;
+typedef double __attribute__((ext_vector_type(4))) rt_d4;
 // The polynomial coefficients (OCML's, as 64-bit patterns) sit in a constant-memory table read with scalar loads: an
-// s_load_dwordx16 brings eight of them into SGPRs with ONE scalar instruction, where immediates would take two s_mov_b32 each
+// s_load_dwordx8 brings four of them into SGPRs with ONE scalar instruction, where immediates would take two s_mov_b32 each
 // (the scalar unit is shared by the CU's four SIMDs and is ~60 % busy in this kernel: measured, immediates made the kernel slower).
 // The two Horner chains are independent, so their steps ALTERNATE (a dependent v_fma_f64 waits for its predecessor; the other
-// chain's step fills the gap), and the coefficients come in four 64-byte groups laid out for that order - atan c0..7 | atan
-// c8..11, asin c0..3 | atan c12..15, asin c4..7 | atan c16..19, asin c8..11 - each fetched by ONE s_load_dwordx16 a segment
-// ahead of its use, the first before the quotient's dependent chain.
+// chain's step fills the gap), and the coefficients come in eight 32-byte groups laid out for that order - atan c0..3 | atan c4..7 |
+// then two steps of each chain per group: atan c8, asin c0, atan c9, asin c1 | ... - each fetched two groups ahead of its use
+// (one ahead: -0.4 %, profiles/r03_ab_log.md), the first two before the quotient's dependent chain.  (Round 2 fetched 64-byte
+// groups: 32 scalar registers of coefficients at the kernel's scalar-pressure peak, where the kernel had none to spare; this way
+// it is 24.)
+#define RT_TRIG_AHEAD 2u
 __constant__ unsigned long long RT_TRIG_BITS[32] = {
-    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull, 0x3f7d6d43a595c56full, 0xbf8c6ea4a57d9582ull,
-    0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull,
-    0x3fa2c15b5711927aull, 0xbfa59976e82d3ff0ull, 0x3fa82d5d6ef28734ull, 0xbfaae5ce6a214619ull,
-    0x3fa059859fea6a70ull, 0xbf90a5a378a05eafull, 0x3f94052137024d6aull, 0x3f7ab3a098a70509ull,
-    0x3fae1bb48427b883ull, 0xbfb110e48b207f05ull, 0x3fb3b13657b87036ull, 0xbfb745d119378e4full,
-    0x3f88ed60a300c8d2ull, 0x3f8c6fa84b77012bull, 0x3f91c6c111dccb70ull, 0x3f96e89f0a0adacfull,
-    0x3fbc71c717e1913cull, 0xbfc2492492376b7dull, 0x3fc99999999952ccull, 0xbfd5555555555523ull,
-    0x3f9f1c72c668963full, 0x3fa6db6db41ce4bdull, 0x3fb333333336fd5bull, 0x3fc5555555555380ull};
+    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull,
+    0x3f7d6d43a595c56full, 0xbf8c6ea4a57d9582ull, 0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull,
+    0x3fa2c15b5711927aull, 0x3fa059859fea6a70ull, 0xbfa59976e82d3ff0ull, 0xbf90a5a378a05eafull,
+    0x3fa82d5d6ef28734ull, 0x3f94052137024d6aull, 0xbfaae5ce6a214619ull, 0x3f7ab3a098a70509ull,
+    0x3fae1bb48427b883ull, 0x3f88ed60a300c8d2ull, 0xbfb110e48b207f05ull, 0x3f8c6fa84b77012bull,
+    0x3fb3b13657b87036ull, 0x3f91c6c111dccb70ull, 0xbfb745d119378e4full, 0x3f96e89f0a0adacfull,
+    0x3fbc71c717e1913cull, 0x3f9f1c72c668963full, 0xbfc2492492376b7dull, 0x3fa6db6db41ce4bdull,
+    0x3fc99999999952ccull, 0x3fb333333336fd5bull, 0xbfd5555555555523ull, 0x3fc5555555555380ull};
 __device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) {
   rt_trig_kptr K = (rt_trig_kptr)(const void *)RT_TRIG_BITS;
   asm volatile("" : "+s"(K));                        // opaque: the reads below stay scalar LOADS instead of being folded back into immediates
-  const rt_d8 k0 = *(const rt_d8 __attribute__((address_space(4))) *)K;
+#define RT_TRIG_GROUP(I) (*(const rt_d4 __attribute__((address_space(4))) *)(K + 4 * (I)))
+  rt_d4 g[8];
+  g[0] = RT_TRIG_GROUP(0); g[1] = RT_TRIG_GROUP(1);
   const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
   const double hi = __builtin_fmax(ax, ay), lo = __builtin_fmin(ax, ay);
   const double q = rt_div(lo, hi);                                   // in [0,1]; 0/0 (both zero) handled below
@@ -301,21 +308,21 @@ __device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, doub
   const double t = __builtin_fma(yw, -0.5, 0.5);                     // (1 - |w|) / 2
   const bool big = (yw >= 0.5);
   const double r = big ? t : w * w;
-  const rt_d8 k1 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 8);
-  double p = k0[0];
+  g[2] = RT_TRIG_GROUP(2);
+  double p = g[0][0];
+  p = rt_fma_k(p, z, g[0][1]); p = rt_fma_k(p, z, g[0][2]); p = rt_fma_k(p, z, g[0][3]);
+  g[3] = RT_TRIG_GROUP(3);
+  p = rt_fma_k(p, z, g[1][0]); p = rt_fma_k(p, z, g[1][1]); p = rt_fma_k(p, z, g[1][2]); p = rt_fma_k(p, z, g[1][3]);
+  double pa = 0.0;
 #pragma unroll
-  for (uint32_t i = 1; i < 8; i++) p = rt_fma_k(p, z, k0[i]);
-  const rt_d8 k2 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 16);
-  double pa = k1[4];
-  p = rt_fma_k(p, z, k1[0]); pa = rt_fma_k(pa, r, k1[5]);
-  p = rt_fma_k(p, z, k1[1]); pa = rt_fma_k(pa, r, k1[6]);
-  p = rt_fma_k(p, z, k1[2]); pa = rt_fma_k(pa, r, k1[7]);
-  p = rt_fma_k(p, z, k1[3]);
-  const rt_d8 k3 = *(const rt_d8 __attribute__((address_space(4))) *)(K + 24);
-#pragma unroll
-  for (uint32_t i = 0; i < 4; i++) { p = rt_fma_k(p, z, k2[i]); pa = rt_fma_k(pa, r, k2[4 + i]); }
-#pragma unroll
-  for (uint32_t i = 0; i < 4; i++) { p = rt_fma_k(p, z, k3[i]); pa = rt_fma_k(pa, r, k3[4 + i]); }
+  for (uint32_t i = 2; i < 8; i++) {                                 // group i: atan step, asin step, atan step, asin step
+    if (i + RT_TRIG_AHEAD < 8u) g[i + RT_TRIG_AHEAD] = RT_TRIG_GROUP(i + RT_TRIG_AHEAD);
+    p = rt_fma_k(p, z, g[i][0]);
+    pa = (i == 2u) ? g[i][1] : rt_fma_k(pa, r, g[i][1]);
+    p = rt_fma_k(p, z, g[i][2]);
+    pa = rt_fma_k(pa, r, g[i][3]);
+  }
+#undef RT_TRIG_GROUP
   // atan2: quadrant and special cases
   double a = __builtin_fma(q, z * p, q);                             // atan(q), q in [0,1]
   a = (ay > ax) ? (M_PI / 2.0 - a) : a;
@@ -413,7 +420,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
   // (tile, row block) with a shift when row blocks per tile is a power of two (the 16-row tiles of the
   // multi-GPU plan), trivially for a single tile (a whole frame), else with one wave-uniform division.
-  const uint32_t tile_x = blockIdx.x + L.bx0, by = blockIdx.y + L.by0;   // fix-up launches cover part of the grid (rt_device.h)
+  const uint32_t tile_x = blockIdx.x, by = blockIdx.y;
   uint32_t tile_i, row_block;
   if (L.n_tiles == 1u) { tile_i = 0u; row_block = by; }
   else if (L.rb_shift != ~0u) { tile_i = by >> L.rb_shift; row_block = by & ((1u << L.rb_shift) - 1u); }
@@ -425,7 +432,6 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   P.frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + P.trow;   // frame row
   P.lrow = tile_i * L.tile_rows + P.trow;                                    // row in this call's output band
   P.valid = (P.px < L.w) && (P.trow < L.tile_rows) && (P.frow < L.h);
-  P.valid = P.valid && (P.px - L.win_x0 < L.win_w) && (P.frow - L.win_y0 < L.win_h);
   P.rows_valid = 0u;                                   // (product kernel only)
   P.sky = false; P.run = 1u; P.cand = 0u;
   return P;
@@ -502,12 +508,37 @@ __device__ __forceinline__ rt_geom_pair rt_load_geom_pair32(geom_kptr tab, uint3
   return rt_geom_pair{rt_geom{v[0], v[1], v[2], v[3]}, rt_geom{v[4], v[5], v[6], v[7]}};
 }
 
-template <bool REFRACT, bool COUNT, bool GRID, bool SS2>
+#if !RT_STRICT
+// The launch record as the COLD paths read it: straight from the kernarg segment at the point of use (the kernel's only argument lies
+// at its start), behind an opaque copy of the pointer, so that a field only the rare paths need is not loaded at kernel entry and
+// held in scalar registers across the whole trace (the kernel has none to spare).
+__device__ __forceinline__ const rt_launch __attribute__((address_space(4))) *rt_cold_args() {
+  const rt_launch __attribute__((address_space(4))) *K = (const rt_launch __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(K));
+  return K;
+}
+// Append this work-item's sample to the launch's mark list (the cold end of the samplers' boundary test, a handful of samples per frame): entry = sample x |
+// sample y << 20 | frame of the batch << 40; the counter of THIS launch is marks[marks_slot] (rt_api.hip alternates two, so that
+// rt_retrace can clear the next launch's while it reads its own); beyond the list's capacity only the count grows and rt_retrace
+// traces every sample of the launch.
+template <bool SS2>
+__device__ __forceinline__ void rt_mark_append(const rt_pixel &P) {
+  const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();
+  if (!P.valid || (K->mark_flags & RT_MARK_NEVER)) return;
+  const uint32_t sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px, sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
+  uint32_t *const marks = K->marks;
+  const uint32_t i = atomicAdd(marks + K->marks_slot, 1u);
+  if (i < K->marks_cap) ((unsigned long long *)(marks + 4))[i] = (unsigned long long)sx | ((unsigned long long)sy << 20) | ((unsigned long long)blockIdx.z << 40);
+}
+#endif
+
+template <bool REFRACT, bool COUNT, bool GRID, bool SS2, bool ITEM = false>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull_lds, [[maybe_unused]] const rt_geom cull0, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
                                             [[maybe_unused]] double blk_y1, v3 p, v3 d, double rgb[3], uint32_t cnt[3],
-                                            [[maybe_unused]] bool is_probe, [[maybe_unused]] uint32_t cand_host) {
+                                            [[maybe_unused]] bool is_probe, [[maybe_unused]] uint32_t cand_host,
+                                            [[maybe_unused]] uint32_t own_sx = 0u, [[maybe_unused]] uint32_t own_sy = 0u) {
 #ifdef RT_TESTING
   uint32_t probe_n = 0;                                  // test build: nodes of this sample's ray tree recorded so far
   double probe_li = 0.0;
@@ -600,7 +631,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           const uint32_t jj = j < NLOOP ? j : 0u;
           double c0 = cull0.ox, c1 = cull0.oy, c2 = cull0.oz, c3 = cull0.r2;
           // (explicit address spaces: the compiler otherwise selects the POINTER and issues one flat load for both cases)
-          if (cull_lds_on) {
+          if constexpr (ITEM) {
+          } else if (cull_lds_on) {
             const rt_geom __attribute__((address_space(3))) *g = (const rt_geom __attribute__((address_space(3))) *)cull_lds + jj;
             c0 = g->ox; c1 = g->oy; c2 = g->oz; c3 = g->r2;
           } else if (base != 0u) {
@@ -612,6 +644,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           // the conjunction in vector registers instead: ~15 more vector instructions per wave in the many-sphere variant)
           unsigned long long m = __ballot(j < NLOOP) & __ballot(cr.ox * L.proj_d <= blk_x1) & __ballot(cr.oy * L.proj_d >= blk_x0) &
                                  __ballot(cr.oz * L.proj_d <= blk_y1) & __ballot(cr.r2 * L.proj_d >= blk_y0);
+          // (rt_retrace: a wave's lanes hold unrelated samples and only some of them run - no wave-wide cull, every sphere in scene order)
+          if constexpr (ITEM) m = (NLOOP - base >= 64u) ? ~0ull : ((1ull << (NLOOP - base)) - 1ull);
           while (m) {
             const uint32_t i = base + (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
@@ -725,7 +759,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
       if (true) { ret[0] = ht; ret[1] = (double)hcode; ret[2] = 0.0; } else
 #endif
       if (hcode < 0) {                                // main.js:231 (with a flat sky of constant colour: that sky's pixel term, see rt_api.hip bind_kernel)
+#if RT_STRICT
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
+#else
+        // (read where it is used, from the kernarg segment: six scalar registers less across the whole loop)
+        { const rt_launch __attribute__((address_space(4))) *K = rt_cold_args(); ret[0] = K->miss_color[0]; ret[1] = K->miss_color[1]; ret[2] = K->miss_color[2]; }
+#endif
 #ifdef RT_TESTING
         if (is_probe && probe_n < RT_PROBE_NODES) {
           double *q = L.probe + (size_t)(probe_n++) * RT_PROBE_WORDS;
@@ -758,6 +797,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #else
         const int kind = m.sampler_kind;
 #endif
+#if RT_STRICT
         if (kind == RT_SAMPLER_TEXTURE) {
           double t_at, t_as;
           rt_atan2_asin(-n.z, -n.x, -n.y, &t_at, &t_as);
@@ -778,13 +818,76 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const int c = to_int32_bit0(u * m.c[6]) ^ to_int32_bit0(v * m.c[7]);
           col[0] = m.c[3 * c]; col[1] = m.c[3 * c + 1]; col[2] = m.c[3 * c + 2];
+#else
+        // ---- Texture (main.js:143-145, 343-351, u, v of :446-447) and sphere-checker (main.js:126-133, its own u, v), and the
+        // boundary marks.
+        // A sampler coordinate x = u * frequency decides a texel (main.js:344-347) or a checker parity (main.js:129-130) by its integer
+        // part, and this kernel's u, v differ from the reference's in their last bits (its hit point and normal do).  A sample with a
+        // coordinate within L.flag_tol (RT_FLAG_T1 x the scene's largest sampler frequency: 1e-9 for the reference's checker) of an
+        // integer is decided in the reference by the last bits of ITS arithmetic: it is appended to the launch's mark list and
+        // traced again, operation for operation, by the strict build's rt_retrace (rt_api.hip).  The test on the hot path is integer work on the bits of x + 1.5 * 2^32, a sum whose ulp
+        // is 2^-20: its mantissa holds floor(x) (from bit 20 up) - the texel index, the checker parity - and 20 fraction bits;
+        // "fraction within 2^-20 of 0 or 1" (6e-6 of the hits) sends the sample to the precise test, which also takes floor(x)
+        // again (the sum rounds a fraction above 1 - 2^-21 up).  (Checker frequencies outside [0, 2^31), where the sum does not hold
+        // ToInt32's parity, make the scene a strict-kernel scene: rt_api.hip.)
+        // RT_XY_INDEX: iu, iv = floor(xu), floor(xv) and the boundary mark
+#define RT_XY_INDEX(XU, XV)                                                                                        \
+          const unsigned long long su = __builtin_bit_cast(unsigned long long, (XU) + 6442450944.0), sv = __builtin_bit_cast(unsigned long long, (XV) + 6442450944.0);   \
+          uint32_t iu = __builtin_amdgcn_alignbit((uint32_t)(su >> 32), (uint32_t)su, 20u) ^ 0x80000000u;       /* floor(x) for x in [0, 2^31) ... */ \
+          uint32_t iv = __builtin_amdgcn_alignbit((uint32_t)(sv >> 32), (uint32_t)sv, 20u) ^ 0x80000000u;       \
+          /* ... unless the fraction is within 2^-20 of an integer <=> the 20 fraction bits are 0xfffff, 0 or 1 (NaN, infinity: 0) */ \
+          if (RT_AB_MARK_COND(min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u)) {           \
+            RT_PIN();                                                                                             \
+            iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
+            const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
+            const double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol;                                 \
+            if (!((__builtin_fabs((XU) - __builtin_rint(XU)) >= tol) & (__builtin_fabs((XV) - __builtin_rint(XV)) >= tol))) {   /* NaN: marked */ \
+              uint32_t t3 = threadIdx.x;                                                                          \
+              asm volatile("" : "+v"(t3));                                                                        \
+              rt_mark_append<SS2>(rt_pixel_of<SS2>(L, t3));                                                        \
+            }                                                                                                     \
+          }
+#ifdef RT_AB_NO_MARK_TEST     /* timing experiments only (profiles/ab_build.sh) */
+#define RT_AB_MARK_COND(C) false
+#else
+#define RT_AB_MARK_COND(C) (C)
+#endif
+        if (kind == RT_SAMPLER_TEXTURE) {
+          double t_at, t_as;
+          rt_atan2_asin(-n.z, -n.x, -n.y, &t_at, &t_as);
+          const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:446 (q6: two divisions)
+          const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:447
+          const rt_texture_desc td = tex[m.texture];
+          const double xu = u * (double)td.width, xv = v * (double)td.height;
+          // max(0, ceil(x) - 1) (main.js:344-345) is floor(x) for every x >= 0 that is not an integer, and the integers are marked:
+          // the index comes out of the fixed-point sum (u, v in [0, 1]; widths and heights <= 16384)
+          RT_XY_INDEX(xu, xv)
+          const uint32_t xi = min(iu, td.width - 1u), yi = min(iv, td.height - 1u);   // memory safety only; u,v <= 1
+          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+          col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
+          col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
+        } else if (kind == RT_SAMPLER_CHECKER) {
+          double t_at, t_as;
+          rt_atan2_asin(-n.y, -n.x, -n.z, &t_at, &t_as);
+          const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
+          const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
+          const double xu = u * m.c[6], xv = v * m.c[7];
+          RT_XY_INDEX(xu, xv)
+          const int c = (int)((iu ^ iv) & 1u);                       // the parity of floor(x) = ToInt32(x) & 1 for x in [0, 2^31)
+          col[0] = m.c[3 * c]; col[1] = m.c[3 * c + 1]; col[2] = m.c[3 * c + 2];
+#undef RT_XY_INDEX
+#undef RT_AB_MARK_COND
+#endif
         } else if (kind == RT_SAMPLER_STARS) {
           // the sample's index in the FRAME (not in this call's tiles), recomputed from the work-item id so that it
           // costs no register outside this branch; `path` is the node's position in the ray tree
-          uint32_t t3 = threadIdx.x;
-          asm volatile("" : "+v"(t3));
-          const rt_pixel P = rt_pixel_of<SS2>(L, t3);
-          const uint32_t sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px, sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
+          uint32_t sx = own_sx, sy = own_sy;         // rt_retrace hands the sample over
+          if constexpr (!ITEM) {
+            uint32_t t3 = threadIdx.x;
+            asm volatile("" : "+v"(t3));
+            const rt_pixel P = rt_pixel_of<SS2>(L, t3);
+            sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px; sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
+          }
           const unsigned long long pix = (unsigned long long)sy * (SS2 ? 2u * L.w : L.w) + sx;
           const uint32_t path = REFRACT ? tree_path : (1u << level);
           double c = star_uniform((uint32_t)pix, (uint32_t)(pix >> 32), path);
@@ -1375,7 +1478,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     uint32_t px2 = P1.px - ((tid2 >> 6) * 8u + (lane2 & 7u)) + xr;
     for (uint32_t t = 0; t < n_run; t++, px2 += RT_TILE_W) {
 #if RT_STRICT
-      const bool row_ok2 = (px2 - L.win_x0 < L.win_w) && (frow2 - L.win_y0 < L.win_h) && trow2 < L.tile_rows && frow2 < L.h;
+      const bool row_ok2 = trow2 < L.tile_rows && frow2 < L.h;
 #else
       const bool row_ok2 = trow2 < P1.rows_valid;      // rows of the block inside its tile and the frame (from the table entry)
 #endif
@@ -1406,8 +1509,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     for (uint32_t t = 0; t < n_run; t++, x0 += RT_TILE_W) {
       const uint32_t in_row = (x0 + 8u <= L.w) ? 6u : ((x0 + 4u <= L.w) ? 3u : 0u);
 #if RT_STRICT
-      // a window's columns are whole 8-pixel groups (rt_api.hip), so the group's first pixel decides
-      const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h) && (x0 - L.win_x0 < L.win_w) && (P1.frow - L.win_y0 < L.win_h);
+      const bool row_ok = (P1.trow < L.tile_rows) && (P1.frow < L.h);
 #else
       const bool row_ok = P1.trow < P1.rows_valid;
 #endif
@@ -1425,13 +1527,106 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   }
 }
 
+#if RT_STRICT
+// rt_retrace - the second, list-driven launch of a product frame (strict build only).  Its items are
+//   * the samples the product launch marked (L.marks: a sampler coordinate within rounding of a texel / checker boundary),
+//   * the centre row and the centre column of an odd sample grid that fall into this call's tiles: x - w/2 + 0.5 == 0 there
+//     (main.js:186), so the primary ray - and every ray it spawns that stays in that plane - lies in a coordinate plane through the
+//     camera, a sphere centred on that plane is met with a normal component of exactly 0, and u or v lands exactly ON a boundary,
+//   * every sample of the call when the list overflowed (or the test build asks for it);
+// each is traced with the reference's own operation sequence - trace_pixel in ITEM mode: every sphere in the scene's own order,
+// materials read from HBM, no wave-wide step (a wave's lanes hold unrelated samples) - and stored where the product launch
+// stored it (band, RGB24 band, or its row of the frame in scatter mode).  With supersample 2 the pixel's four samples are all
+// traced (the product launch kept only their average).  A grid-stride loop: the number of items is only known on the device.
+// Work-item 0 clears the NEXT launch's counter and publishes this launch's count to the host (rt_api.hip skips this launch from
+// then on if a frame of this scene, camera, size and tile set has no item at all).
+template <bool REFRACT, bool SS2>
+__global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
+  const uint32_t count = L.marks[L.marks_slot];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    L.marks[L.marks_slot ^ 1u] = 0u;
+    if (L.marks_known) __hip_atomic_store(L.marks_known, count + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const uint32_t band_rows = L.n_tiles * L.tile_rows;
+  const bool everything = count > L.marks_cap || L.retrace_all != 0u;
+  const unsigned long long n_list = everything ? 0ull : count;
+  const unsigned long long n_row = (!everything && L.centre_row != ~0u) ? (unsigned long long)L.w * L.n_frames : 0ull;
+  const unsigned long long n_col = (!everything && L.centre_col != ~0u) ? (unsigned long long)band_rows * L.n_frames : 0ull;
+  const unsigned long long n_all = everything ? (unsigned long long)band_rows * L.w * L.n_frames : 0ull;
+  const unsigned long long total = n_list + n_row + n_col + n_all;
+  const unsigned long long *list = (const unsigned long long *)(L.marks + 4);
+  const rt_mtl *mtl = (const rt_mtl *)L.lds_image;                         // (HBM: nothing is staged here)
+  const rt_texture_desc *tex = (const rt_texture_desc *)((const char *)L.lds_image + (size_t)L.n_objects * sizeof(rt_mtl));
+  for (unsigned long long i = (unsigned long long)blockIdx.x * RT_WG_THREADS + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * RT_WG_THREADS) {
+    uint32_t px, frow, lrow, f;
+    bool have_lrow = false;
+    lrow = 0u;
+    if (i < n_list) {
+      const unsigned long long e = list[i];
+      const uint32_t sx = (uint32_t)(e & 0xfffffu), sy = (uint32_t)((e >> 20) & 0xfffffu);
+      f = (uint32_t)(e >> 40);
+      px = SS2 ? sx >> 1 : sx; frow = SS2 ? sy >> 1 : sy;
+    } else if (i < n_list + n_row) {
+      const unsigned long long k = i - n_list;
+      f = (uint32_t)(k / L.w); px = (uint32_t)(k - (unsigned long long)f * L.w); frow = L.centre_row;
+    } else {
+      unsigned long long k = i - n_list - n_row;
+      if (!everything) { f = (uint32_t)(k / band_rows); lrow = (uint32_t)(k - (unsigned long long)f * band_rows); px = L.centre_col; }
+      else { f = (uint32_t)(k / ((unsigned long long)band_rows * L.w)); k -= (unsigned long long)f * band_rows * L.w; lrow = (uint32_t)(k / L.w); px = (uint32_t)(k - (unsigned long long)lrow * L.w); }
+      const uint32_t tile_i = lrow / L.tile_rows, trow = lrow - tile_i * L.tile_rows;
+      frow = (L.tile_first + tile_i * L.tile_stride) * L.tile_rows + trow;
+      have_lrow = true;
+    }
+    if (!have_lrow) {                                    // the row's place in this call's band, if the call renders it at all
+      const uint32_t t = frow / L.tile_rows;
+      if (t < L.tile_first || (t - L.tile_first) % L.tile_stride != 0u || (t - L.tile_first) / L.tile_stride >= L.n_tiles) continue;
+      lrow = ((t - L.tile_first) / L.tile_stride) * L.tile_rows + (frow - t * L.tile_rows);
+    }
+    if (px >= L.w || frow >= L.h || f >= L.n_frames) continue;
+    uint32_t sum[3] = {0u, 0u, 0u};
+    for (uint32_t sub = 0; sub < (SS2 ? 4u : 1u); sub++) {
+      const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px, sy = SS2 ? 2u * frow + (sub >> 1) : frow;
+      // A1 primary ray (main.js:186-193), literally
+      const double d0 = ((double)sx - L.proj_w) + 0.5, d1 = (L.proj_h - (double)sy) - 0.5, d2 = L.proj_d;
+      const v3 o = mk(L.cam_origin[0], L.cam_origin[1], L.cam_origin[2]);
+      const v3 target = mk(o.x + L.cam_axis_x[0] * d0 + L.cam_axis_y[0] * d0 + L.cam_axis_z[0] * d0,
+                           o.y + L.cam_axis_x[1] * d1 + L.cam_axis_y[1] * d1 + L.cam_axis_z[1] * d1,
+                           o.z + L.cam_axis_x[2] * d2 + L.cam_axis_y[2] * d2 + L.cam_axis_z[2] * d2);
+      double rl;
+      const v3 ray = unit(mk(target.x - o.x, target.y - o.y, target.z - o.z), &rl);
+      double rgb[3];
+      uint32_t cnt[3] = {0u, 0u, 0u};
+      trace_pixel<REFRACT, false, false, SS2, true>(L, mtl, tex, nullptr, nullptr, rt_geom{0.0, 0.0, 0.0, 0.0}, 0u, 0.0, 0.0, 0.0, 0.0, o, ray, rgb, cnt, false, 0u, sx, sy);
+      sum[0] += to_byte(rgb[0]); sum[1] += to_byte(rgb[1]); sum[2] += to_byte(rgb[2]);
+    }
+    if (SS2) { sum[0] = (sum[0] + 2u) >> 2; sum[1] = (sum[1] + 2u) >> 2; sum[2] = (sum[2] + 2u) >> 2; }
+    if (L.scatter) L.out_frames[f][(size_t)frow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
+    else if (!L.rgb24) L.out[(size_t)f * L.frame_stride + (size_t)lrow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
+    else {
+      uint8_t *o8 = (uint8_t *)(L.out + (size_t)f * L.frame_stride) + ((size_t)lrow * L.w + px) * 3u;
+      o8[0] = (uint8_t)sum[0]; o8[1] = (uint8_t)sum[1]; o8[2] = (uint8_t)sum[2];
+    }
+  }
+}
+#endif
+
 }  // namespace
+
+#if RT_STRICT
+// Host-side launcher of rt_retrace (n_wg workgroups of RT_WG_THREADS).  Returns a hipError_t as int.
+extern "C" int rt_launch_retrace(const rt_launch *L, int refract, int ss2, unsigned n_wg, hipStream_t stream) {
+  const dim3 grid(n_wg ? n_wg : 1u), block(RT_WG_THREADS);
+  if (!refract) { if (!ss2) hipLaunchKernelGGL((rt_retrace<false, false>), grid, block, 0, stream, *L); else hipLaunchKernelGGL((rt_retrace<false, true>), grid, block, 0, stream, *L); }
+  else          { if (!ss2) hipLaunchKernelGGL((rt_retrace<true, false>), grid, block, 0, stream, *L);  else hipLaunchKernelGGL((rt_retrace<true, true>), grid, block, 0, stream, *L); }
+  return (int)hipGetLastError();
+}
+#endif
 
 // Host-side launcher for this translation unit's kernels.  Returns a hipError_t as int.
 extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss2, unsigned lds_bytes, hipStream_t stream) {
   // x: 32-pixel tiles across the frame; y: tiles x row blocks (8 rows, or 2 when supersampling); z: frames
   (void)ss2;
-  // (a fix-up launch of the strict kernel covers part of that grid: L->grid_x / grid_y, when set)
+  // (the product launch is flat: L->grid_x workgroups, one per launch-table entry)
   const dim3 grid(L->grid_x ? L->grid_x : (L->order ? L->tiles_x * L->n_tiles * L->rb_per_tile : L->tiles_x),
                   L->grid_y ? L->grid_y : (L->order ? 1u : L->n_tiles * L->rb_per_tile), L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)

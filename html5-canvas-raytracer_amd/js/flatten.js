@@ -6,7 +6,7 @@ const fs = require('fs');
 const path = require('path');
 const S = require('./scene.js');
 
-const RT_SCENE_MAGIC = 0x31535452, RT_ABI_VERSION = 1;
+const RT_SCENE_MAGIC = 0x31535452, RT_ABI_VERSION = 2;
 const HEADER_BYTES = 208, SPHERE_BYTES = 192, TEXDESC_BYTES = 16;
 
 function flattenScene(scene) {

@@ -104,6 +104,7 @@ napi_value make_result(napi_env env, args *a) {
   napi_create_double(env, (double)a->st.rays, &v); napi_set_named_property(env, stats, "rays", v);
   napi_create_double(env, (double)a->st.shadow_rays, &v); napi_set_named_property(env, stats, "shadow_rays", v);
   napi_create_double(env, (double)a->st.sphere_tests, &v); napi_set_named_property(env, stats, "sphere_tests", v);
+  napi_create_double(env, (double)a->st.exact_samples, &v); napi_set_named_property(env, stats, "exact_samples", v);
   { char rep[96]; napi_value sv; if (rt_elapsed_report(&a->st, rep, sizeof rep) > 0) { napi_create_string_utf8(env, rep, NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "report", sv); }
     napi_create_string_utf8(env, rt_build_id(), NAPI_AUTO_LENGTH, &sv); napi_set_named_property(env, stats, "build", sv); }
   napi_set_named_property(env, res, "stats", stats);

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(HERE, "csrc", "librt_hip
 TEST_LIB_PATH = os.path.join(HERE, "csrc", "librt_hip_test.so")
 
 RT_SCENE_MAGIC = 0x31535452
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 HEADER_BYTES, SPHERE_BYTES, TEXDESC_BYTES = 208, 192, 16
 SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS = 0, 1, 2, 3
 
@@ -133,7 +133,7 @@ class RtTiles(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("pixels", C.c_uint64), ("rays", C.c_uint64),
-                ("shadow_rays", C.c_uint64), ("sphere_tests", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("sphere_tests", C.c_uint64), ("exact_samples", C.c_uint64)]
 
 
 # every symbol include/rt_hip.h declares: (restype, argtypes)
@@ -264,7 +264,7 @@ class Renderer:
 
 
 def build_id(lib=None):
-    """`const build = '741'` (main.js:3) + the library's revision, e.g. '741.r2'."""
+    """`const build = '741'` (main.js:3) + the library's revision, e.g. '741.r3'."""
     return (lib or load_library()).rt_build_id().decode()
 
 

@@ -31,12 +31,12 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 #define RT_SCENE_MAGIC 0x31535452u /* "RTS1" little endian */
 /* `const build = '741'` (main.js:3): the reference build whose per-pixel path this library reproduces, and this library's own
  * revision of it; rt_build_id() returns "<reference build>.<revision>". */
 #define RT_REFERENCE_BUILD "741"
-#define RT_LIBRARY_REVISION "r2"
+#define RT_LIBRARY_REVISION "r3"
 
 #define RT_MAX_OBJECTS  256u
 #define RT_MAX_LIGHTS   16u
@@ -132,6 +132,9 @@ typedef struct rt_stats {
   uint64_t rays;           /* intersectWorld invocations with segs>0 (main.js:220-221) */
   uint64_t shadow_rays;    /* lights tested for occlusion (main.js:293-304) */
   uint64_t sphere_tests;   /* intersectSphere calls (main.js:228,296) */
+  uint64_t exact_samples;  /* samples the product kernel traced a second time with the reference's own operation sequence:
+                            * a sampler coordinate on a texel / checker boundary (main.js:129-130, 344-347) up to rounding, or the
+                            * centre row / column of an odd sample grid (main.js:186: x - w/2 + 0.5 == 0).  Every stats call. */
 } rt_stats;
 
 enum {
@@ -152,7 +155,7 @@ void rt_shutdown(void);
 int rt_device_count(void);            /* GPUs in use after rt_init, or a negative rt_status */
 const char *rt_last_error(void);
 uint32_t rt_abi_version(void);
-const char *rt_build_id(void);        /* RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION, e.g. "741.r2" (main.js:3) */
+const char *rt_build_id(void);        /* RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION, e.g. "741.r3" (main.js:3) */
 
 /* Validate a scene blob without touching a GPU (host logic; usable in CPU-only tests). */
 int rt_scene_validate(const void *scene_blob, size_t blob_bytes);

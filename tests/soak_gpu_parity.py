@@ -113,12 +113,14 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--many-spheres", action="store_true", help="25..200 spheres, depth >= 2, larger frames: the shadow-grid / bounce-table variants")
     ap.add_argument("--degenerate-lights", action="store_true", help="also place lights at the centres of the ground/sky spheres ([0,0,0] is ON the ground sphere)")
+    ap.add_argument("--windowed", action="store_true", help="narrow cones: each scene as two 8-row tiles of a 3840x2160 or 7680x4320 frame (the launch table's "
+                    "sky blocks, shadow masks and candidates at the headline's block size of ~0.5 degrees)")
     args = ap.parse_args()
     lib = rt_host.load_library()
     assert lib.rt_init(1) == 0, lib.rt_last_error()
     import ctypes as C
     t0 = time.time()
-    tot = {k: {"channels": 0, "off_by_one": 0, "flipped_pixels": 0, "worst": 0, "scenes_with_flips": []} for k in ("fma", "strict")}
+    tot = {k: {"channels": 0, "off_by_one": 0, "flipped_pixels": 0, "worst": 0, "scenes_with_flips": [], "exact_samples": 0} for k in ("fma", "strict")}
     pixels = 0
     # a soak that is cut short (timeout's SIGTERM, a GPU box's limit) still reports what it covered
     import signal
@@ -133,7 +135,8 @@ def main():
         for k, T in tot.items():
             out[k] = {"off_by_one_channel_fraction": T["off_by_one"] / max(T["channels"], 1), "flipped_pixels": T["flipped_pixels"],
                       "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
-                      "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"])}
+                      "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"]),
+                      "exact_samples": T["exact_samples"]}
         text = json.dumps(out, indent=1)
         if args.out:
             open(args.out, "w").write(text)
@@ -143,17 +146,30 @@ def main():
         if stop["now"]:
             break
         scene, w, h = draw_scene(seed, args.degenerate_lights, args.many_spheres)
+        tiles = rt_host.RtTiles(h, 0, 1, 1)
+        rows = None
+        if args.windowed:
+            wrng = random.Random(seed ^ 0x5bd1e995)
+            w, h = wrng.choice([(3840, 2160), (3840, 2160), (7680, 4320)])
+            scene["supersample"] = 1
+            n_t = h // 8
+            t0 = wrng.randrange(0, n_t - 1)
+            stride = wrng.randrange(1, n_t - t0)
+            tiles = rt_host.RtTiles(8, t0, stride, 2)
+            rows = [8 * t + k for t in (t0, t0 + stride) for k in range(8)]
         blob = rt_host.flatten_scene(scene)
-        want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h * w, 4).astype(np.int16)
-        pixels += w * h
+        n_px = (len(rows) if rows else h) * w
+        want = np.frombuffer(ou.c_oracle_rows(blob, w, h, rows) if rows else ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(n_px, 4).astype(np.int16)
+        pixels += n_px
         r = rt_host.Renderer(blob, 0, lib)
-        d = lib.rt_alloc_device(0, w * h * 4)
+        d = lib.rt_alloc_device(0, n_px * 4)
         try:
             for name, flags in (("fma", 0), ("strict", rt_host.RT_FLAG_STRICT_FP)):
-                r.render_tiles(w, h, d, rt_host.RtTiles(h, 0, 1, 1), flags=flags, want_stats=True)
-                host = C.create_string_buffer(w * h * 4)
-                assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
-                got = np.frombuffer(host.raw, dtype=np.uint8).reshape(h * w, 4).astype(np.int16)
+                st = r.render_tiles(w, h, d, tiles, flags=flags, want_stats=True)
+                tot[name]["exact_samples"] += st.exact_samples     # samples the second, list-driven strict launch traced again
+                host = C.create_string_buffer(n_px * 4)
+                assert lib.rt_copy_to_host(0, host, d, n_px * 4) == 0
+                got = np.frombuffer(host.raw, dtype=np.uint8).reshape(n_px, 4).astype(np.int16)
                 diff = np.abs(got - want)
                 T = tot[name]
                 T["channels"] += diff.size

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_sizes_match_header(built):
-    assert C.sizeof(rt_host.RtTiles) == 16 and C.sizeof(rt_host.RtStats) == 48
+    assert C.sizeof(rt_host.RtTiles) == 16 and C.sizeof(rt_host.RtStats) == 56
     blob = rt_host.flatten_scene(rt_host.load_scene("h8"))
     magic, ver, total = struct.unpack_from("<IIQ", blob, 0)
-    assert (magic, ver, total) == (rt_host.RT_SCENE_MAGIC, 1, len(blob))
+    assert (magic, ver, total) == (rt_host.RT_SCENE_MAGIC, rt_host.RT_ABI_VERSION, len(blob))
     assert len(blob) == 208 + 8 * 192 + 2 * 24 + 2 * 16 + 2 * 131072
 
 

@@ -26,7 +26,7 @@ console.log(JSON.stringify(out));
 """ % (PKG, PKG, PKG, PKG)
     out = json.loads(subprocess.check_output([ou.node_path(), "-e", js], text=True))
     assert out["exports"] == ["abiVersion", "buildId", "init", "render", "renderAsync", "renderProgressive", "shutdown", "validate"]
-    assert out["abi"] == 1 and out["valid"] is True
+    assert out["abi"] == 2 and out["valid"] is True
     assert out["build"].startswith("741.")                 # `const build = '741'` (main.js:3) + the library's revision
     import torch
     if not torch.cuda.is_available():
