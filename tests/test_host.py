@@ -7,6 +7,7 @@ import re
 import struct
 import subprocess
 
+import numpy as np
 import pytest
 
 import oracle_util as ou
@@ -485,6 +486,126 @@ def test_launch_table_shadow_masks_are_conservative(built, scene, w, h, sample, 
                             bit = (1 << loop_of[j]) if len(loop_of) <= 16 else 1      # more than 16 loop spheres: empty (0) or not (0xffff)
                             assert (smask >> (16 * k)) & bit, (scene, tile_x, frow0, ix, iy, k, j, hex(smask))
     assert named_blocks > 0 and (stated > 0 or not sc["lights"]) and empty >= min_empty * stated, (scene, stated, empty, named_blocks)
+
+
+def _soak_like_scene(seed):
+    import soak_gpu_parity as soak
+    sc, _w, _h = soak.draw_scene(seed, False, False)
+    sc["supersample"] = 1
+    return sc
+
+
+def _horizon_scene():
+    """A block that sees a sphere's SILHOUETTE has hit distances up to the tangent length sqrt(|C|^2 - r^2); rt_tables.cpp bounded it
+    with an inflated radius once (before e31efa6), which is too SHORT by |C| r 1e-7 / tangent - 6e-4 on the horizon of the
+    reference's ground sphere, far above the 1e-6 margins.  A ground with its horizon in the frame and small occluders whose
+    shadows graze the far field."""
+    sc = rt_host.load_scene("h8")
+    keep = [o for o in sc["objects"] if o["r2"] >= 250000.0]          # ground (checker) and sky
+    for k in range(6):
+        keep.append({"origin": [-20.0 + 8.0 * k, 0.6 + 0.3 * k, -30.0 - 2.0 * k], "r2": 0.36 + 0.05 * k,
+                     "mtl": {"color": [1, 0, 0], "albedo": [0, 0.8, 0.3, 0.0, 0.0], "specular_exponent": 50, "refract_index": 1.0, "sampler": {"kind": 0}}})
+    sc["objects"] = sorted(keep, key=lambda o: 4 * 3.141592653589793 * o["r2"] / max(sum((o["origin"][k] - sc["camera"]["origin"][k]) ** 2 for k in range(3)) ** 0.5, 1e-300))
+    sc["lights"] = [[60.0, 3.0, -60.0], [-80.0, 2.0, -20.0]]          # low lights: long shadows towards the horizon
+    return sc
+
+
+@pytest.mark.parametrize("scene,w,h", [
+    ("h8", 256, 144), ("h8", 250, 256), ("cfg2", 256, 144), ("default14", 256, 144), ("lcg64_ss1", 256, 144), ("cfg1", 128, 128),
+    ("horizon", 256, 144), ("horizon", 256, 48),
+    ("soak:11", 160, 90), ("soak:12", 131, 77), ("soak:13", 96, 64), ("soak:14", 256, 144), ("soak:15", 100, 90), ("soak:16", 160, 90),
+    ("soak:17", 64, 48), ("soak:18", 256, 144), ("soak:19", 131, 77), ("soak:20", 160, 90), ("soak:21", 96, 64), ("soak:22", 256, 144)])
+def test_launch_table_statements_hold_for_every_sample_of_every_block(built, scene, w, h):
+    """EXHAUSTIVE form of the two tests above (numpy, every sample of every block of a small frame): what the launch table states
+    about a block - sky (nothing but the background shows), its primary candidates (word 3), per light the spheres that can
+    shadow a primary hit of it (word 2) - is checked against every one of the block's samples: the reference's own ray
+    (main.js:186-193), the reference's root selection (main.js:420-439) for the primary hit and for every shadow ray
+    (main.js:293-304).  Scenes: the BASELINE scenes, a horizon scene for the tangent bound (see _horizon_scene), and scenes and
+    cameras of the soak's generator (cameras inside spheres, wide and narrow fields of view, 1..90 spheres)."""
+    import math
+    lib = rt_host.load_library()
+    sc = _horizon_scene() if scene == "horizon" else (_soak_like_scene(int(scene[5:])) if scene.startswith("soak:") else rt_host.load_scene(scene))
+    sc["supersample"] = 1
+    blob = rt_host.flatten_scene(sc)
+    entries = _launch_table(lib, blob, w, h, (h, 0, 1, 1), 2 | 4)
+    objs, cam = sc["objects"], sc["camera"]
+    N = len(objs)
+    o = np.array(cam["origin"], dtype=np.float64)
+    asum = np.array([cam["axisX"][k] + cam["axisY"][k] + cam["axisZ"][k] for k in range(3)])
+    eps = sc.get("epsilon", 0.001)
+    C3 = np.array([q["origin"] for q in objs], dtype=np.float64)
+    R2 = np.array([q["r2"] for q in objs], dtype=np.float64)
+    lights = [np.array(l, dtype=np.float64) for l in sc["lights"]]
+
+    def dist(a, b):
+        return math.sqrt(sum((a[i] - b[i]) ** 2 for i in range(3)))
+    enclosing = None
+    for e, q in enumerate(objs):
+        lim = math.sqrt(q["r2"]) * (1 - 1e-6)
+        if N > 1 and dist(o, q["origin"]) < lim and all(dist(l, q["origin"]) < lim for l in sc["lights"]) and \
+           all(dist(p["origin"], q["origin"]) + math.sqrt(p["r2"]) < lim for j, p in enumerate(objs) if j != e):
+            enclosing = e
+            break
+    loop_of = np.array([(j - 1 if (enclosing is not None and j > enclosing) else j) for j in range(N)])
+    n_loop = N - (enclosing is not None)
+    pw, ph = w / 2.0, h / 2.0
+    pd = pw / math.tan(sc.get("fovDeg", 60) * math.pi / 180 / 2)
+
+    def hits(org, d):                                          # (P,3) origins / unit directions -> (P,N) distances, main.js:420-439
+        L3 = C3[None, :, :] - org[:, None, :]
+        tca = (d[:, None, :] * L3).sum(axis=2)
+        d2 = (L3 * L3).sum(axis=2) - tca * tca
+        with np.errstate(invalid="ignore"):
+            thc = np.sqrt(R2[None, :] - d2)
+        t0, t1 = tca - thc, tca + thc
+        t = np.where(t0 < eps, t1, t0)
+        return np.where((d2 > R2[None, :]) | (t < eps) | np.isnan(t), np.inf, t)
+    ys, xs = np.mgrid[0:h, 0:w]
+    D = np.stack([asum[0] * (xs - pw + 0.5), asum[1] * (ph - ys - 0.5), np.full(xs.shape, asum[2] * pd)], axis=2).reshape(-1, 3)
+    D = D / np.sqrt((D * D).sum(axis=1))[:, None]
+    O = np.broadcast_to(o, D.shape)
+    T = hits(O, D)
+    best = T.argmin(axis=1)                                    # strict <, first wins (main.js:229)
+    tb = T[np.arange(len(best)), best]
+    miss = ~np.isfinite(tb)
+    HP = O + D * np.where(miss, 0.0, tb)[:, None]
+    blockers = []                                              # per light: (P,N) does sphere j stand between the hit point and the light
+    for lt in lights:
+        sv = lt[None, :] - HP
+        llen = np.sqrt((sv * sv).sum(axis=1))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sv = sv / llen[:, None]
+        B = hits(HP, sv) < llen[:, None]
+        B[np.arange(len(best)), best] = False
+        if enclosing is not None:
+            B[:, enclosing] = False
+        blockers.append(B)
+    best = best.reshape(h, w); miss = miss.reshape(h, w)
+    n_sky = n_named = n_stated = 0
+    for tile_x, valid, frow0, _lrow, sky, run, smask, cands in entries:
+        if not valid:
+            continue
+        x0, x1, y0, y1 = tile_x * 32, min(w, (tile_x + (run if sky else 1)) * 32), frow0, frow0 + valid
+        blk_best, blk_miss = best[y0:y1, x0:x1], miss[y0:y1, x0:x1]
+        if sky:                                               # nothing but the enclosing sphere (or nothing at all) shows
+            n_sky += 1
+            assert (blk_miss | (blk_best == (enclosing if enclosing is not None else -1))).all(), (scene, "sky", tile_x, frow0, run)
+            continue
+        shown = set(np.unique(blk_best[~blk_miss]).tolist()) - {enclosing}
+        if cands:
+            n_named += 1
+            named = [cands & 255] + ([(cands >> 8) & 255] if (cands >> 16) > 1 else [])
+            assert {int(loop_of[j]) for j in shown} <= set(named), (scene, "candidates", tile_x, frow0, sorted(shown), hex(cands))
+        if smask != 0xffffffff:
+            n_stated += 1
+            lit = (~blk_miss) & (blk_best != (enclosing if enclosing is not None else -1))
+            for k in range(len(lights)):
+                Bk = blockers[k].reshape(h, w, N)[y0:y1, x0:x1][lit]
+                need = np.nonzero(Bk.any(axis=0))[0]
+                for j in need:
+                    bit = (1 << int(loop_of[j])) if n_loop <= 16 else 1
+                    assert (smask >> (16 * k)) & bit, (scene, "shadow mask", tile_x, frow0, k, int(j), hex(smask))
+    assert n_sky + n_named + n_stated > 0 or scene.startswith("soak:"), scene
 
 
 @pytest.mark.parametrize("scene,w,h,tiles", [
