@@ -18,10 +18,12 @@
 #include <chrono>
 #include <cmath>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "rt_device.h"
 #include "rt_tables.h"
+#include "rt_tables_gpu.h"
 
 extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, hipStream_t);
@@ -107,15 +109,37 @@ int ensure_device(int d) {
 
 struct rt_scene_dev {
   int device;
+  // Everything the scene keeps in HBM is ONE allocation (`arena`), filled by one copy at upload; the pointers below point into it.
+  // Its last part is the CAMERA BLOCK - what depends on the camera: per ordering the camera-anchored geometry and the cull
+  // rectangles, and (few spheres) the LDS images, whose tails are the cull rectangles - rewritten with one small asynchronous copy
+  // when the camera moves (rt_scene_set_camera).
+  uint8_t *arena = nullptr;
+  size_t arena_bytes = 0;
   void *d_blob;                  // the uploaded scene blob
   rt_texture_desc *d_texdesc;    // RT_MAX_TEXTURES descriptors (zero padded)
-  rt_geom *d_geom;               // geometry tables, two orderings: [A: plain, camera, lights][B: plain, camera, lights]
+  rt_geom *d_geom;               // camera-independent geometry tables, per ordering [plain N | anchored at light k: NL x N]
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
   uint64_t *d_shadow_grid;       // light grids for the product kernel's loop order, or NULL (few spheres)
   uint64_t *d_bounce_table;      // bounce table for the same order, or NULL (few spheres, or depth < 2)
-  uint8_t *d_lds_image;          // per ordering: [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)], the LDS image
+  uint8_t *d_lds_image;          // per ordering: [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)], the LDS image (in the camera block when it holds the rectangles)
+  uint8_t *d_cam;                // the camera block: per ordering [anchored at the camera N | cull rectangles N], then the LDS images when they hold the rectangles
+  size_t cam_bytes;
+  bool has_b;                    // two orderings (an enclosing sphere)
   bool cull_in_lds;
   size_t lds_image_bytes;        // of one ordering
+  uint64_t cam_gen = 1;          // bumped when the camera moves: launch tables and mark counts of an older camera are stale
+  hipStream_t last_stream = nullptr;     // the stream of the scene's last launch; several: launches of this scene are in flight on more than one
+  bool any_launch = false, several_streams = false;
+  hipStream_t cam_stream = nullptr;      // the stream the camera block was last written on, and the event behind that copy
+  hipEvent_t cam_ready = nullptr;
+  // pinned staging for the small copies that follow a camera move (the camera block; a launch table's parameters): a ring of slots,
+  // each guarded by an event recorded behind the copy that read it
+  struct stage_slot { uint8_t *h = nullptr; hipEvent_t done = nullptr; bool used = false; };
+  stage_slot stages[4];
+  size_t stage_bytes = 0;
+  uint32_t stage_next = 0;
+  std::vector<uint8_t> host_blob;        // the scene as uploaded (patched: 1/r per sphere), for rebuilding the camera block
+  std::vector<rt_sphere> host_objects_b; // ordering B of its sphere records
   rt_scene_header hd;            // host copy
   bool refract;                  // any albedo[4] > 0  -> general (binary-tree) kernel variant
   unsigned lds_bytes;
@@ -129,19 +153,29 @@ struct rt_scene_dev {
   std::vector<rt_sphere> host_objects;   // the scene's sphere records (scene order), for the launch table's sky marking
   std::vector<rt_geom> host_cull;
   std::vector<uint32_t> tile_weight;
-  struct order_entry { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t n_entries; uint32_t *d_order; };
+  // One launch table per (frame size, tile set, flags), built on the GPU (rt_tables_gpu.hip) on the stream of the launch that needs
+  // it first and again, in place, when the camera has moved since (cam_gen).  `T` = its device memory; `d_block` = ONE allocation
+  // behind all of T's arrays; `n_blocks` workgroups are launched until the host has seen the number of entries the build published
+  // (`known`: generation << 32 | entries + 1, a pinned host word), from then on exactly that many.
+  struct order_entry {
+    uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands;
+    uint64_t cam_gen; uint32_t n_blocks; size_t hist_words; rt_table_dev T; uint8_t *d_block; volatile unsigned long long *known; hipStream_t built_on; hipEvent_t built;
+    bool shared;                   // launched with on a stream other than the one it was built on
+  };
   std::vector<order_entry> orders;
+  uint32_t order_evict = 0;
+  rt_texture_desc descs[RT_MAX_TEXTURES];
   // Marked samples (rt_device.h, rt_kernel.hip: rt_retrace).  One state per (launch table, stream): the device list the product
   // launch appends to and rt_retrace reads, which of its two counters the next launch uses, and a pinned host word in which
   // rt_retrace publishes how many samples a frame of this scene, camera, size and tile set marks - the same every time, so once it
   // says "none" (and the sample grid has no odd centre) the second launch is skipped.  Launches that share a state share a
   // stream, i.e. they are ordered; mark_mu makes a launch pair one step for the threads of this process.
-  struct mark_state { uint32_t order_index; hipStream_t stream; uint32_t *d_marks; volatile uint32_t *h_known; uint32_t slot; };
+  struct mark_state { uint32_t order_index; hipStream_t stream; uint32_t *d_marks; volatile unsigned long long *h_known; uint32_t slot; };   // *h_known: camera generation << 32 | marks + 1
   std::vector<mark_state> mark_states;
-  uint32_t *h_known_pool = nullptr;      // RT_MARK_STATES pinned words
-  std::mutex mark_mu;
-  std::mutex order_mu;
+  unsigned long long *h_known_pool = nullptr;      // 2 x RT_KNOWN_WORDS pinned words: the mark states', then the launch tables'
+  std::mutex launch_mu;          // a product launch - its table (found or built), the trace launch, rt_retrace - is one step for the threads of this process
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
+  bool needs_strict_scene;       // ... whatever the camera (a light on a surface, a sphere without a radius, exotic checker frequencies)
   double flag_tol;               // RT_FLAG_T1 x the largest sampler frequency of the scene (texture width / height, checker frequencies): rt_device.h
 };
 
@@ -260,6 +294,83 @@ extern "C" int rt_scene_cull_rects(const void *blob, size_t bytes, double *out) 
 }
 
 // ------------------------------------------------------------------------------------ upload
+namespace {
+constexpr size_t RT_KNOWN_WORDS = 256;
+
+void free_order_entry(rt_scene_dev::order_entry &e) {
+  if (e.d_block) (void)hipFree(e.d_block);
+  if (e.built) (void)hipEventDestroy(e.built);
+  e.d_block = nullptr; e.built = nullptr;
+}
+
+// [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)] of ordering `ord`: the workgroup's LDS image
+void fill_lds_image(const rt_scene_dev *s, uint8_t *dst, int ord) {
+  const uint32_t NO = s->hd.n_objects;
+  const rt_sphere *src = ord ? s->host_objects_b.data() : (const rt_sphere *)(s->host_blob.data() + s->hd.objects_offset);
+  rt_mtl *mt = (rt_mtl *)dst;
+  for (uint32_t i = 0; i < NO; i++) {
+    const rt_sphere &o = src[i];
+    rt_mtl &m = mt[i];
+    memset(&m, 0, sizeof m);
+    memcpy(m.origin, o.origin, sizeof m.origin);
+    m.inv_r = o.reserved;                           // 1/r, patched at upload
+    memcpy(m.albedo, o.albedo, sizeof m.albedo);
+    m.specular_exponent = o.specular_exponent; m.refract_index = o.refract_index;
+    m.sampler_kind = o.sampler_kind; m.texture = o.texture;
+    if (o.sampler_kind == RT_SAMPLER_CHECKER) memcpy(m.c, o.checker_color, 6 * sizeof(double));
+    else memcpy(m.c, o.color, 3 * sizeof(double));
+    m.c[6] = o.checker_freq[0]; m.c[7] = o.checker_freq[1];
+  }
+  memcpy(dst + (size_t)NO * sizeof(rt_mtl), s->descs, sizeof s->descs);
+  if (s->cull_in_lds) {
+    rt_geom *cr = (rt_geom *)(dst + (size_t)NO * sizeof(rt_mtl) + sizeof s->descs);
+    for (uint32_t i = 0; i < NO; i++) cr[i] = cull_rect(&s->hd, src[i]);
+  }
+}
+
+// The camera block (rt_scene_dev): per ordering [anchored at the camera {o - cam, |o - cam|^2 - r2} N | primary-ray cull
+// rectangles N], then the LDS images when they hold the rectangles.  `dst`: cam_bytes of host memory.
+void fill_camera_block(const rt_scene_dev *s, uint8_t *dst) {
+  const uint32_t NO = s->hd.n_objects;
+  const int n_ord = s->has_b ? 2 : 1;
+  for (int ord = 0; ord < n_ord; ord++) {
+    const rt_sphere *src = ord ? s->host_objects_b.data() : (const rt_sphere *)(s->host_blob.data() + s->hd.objects_offset);
+    rt_geom *g = (rt_geom *)dst + (size_t)ord * 2u * NO;
+    for (uint32_t i = 0; i < NO; i++) {
+      const double lx = src[i].origin[0] - s->hd.cam_origin[0], ly = src[i].origin[1] - s->hd.cam_origin[1], lz = src[i].origin[2] - s->hd.cam_origin[2];
+      g[i] = rt_geom{lx, ly, lz, (lx * lx + ly * ly + lz * lz) - src[i].r2};
+      g[NO + i] = cull_rect(&s->hd, src[i]);
+    }
+  }
+  if (s->cull_in_lds) {
+    uint8_t *img = dst + (((size_t)n_ord * 2u * NO * sizeof(rt_geom) + 255u) & ~(size_t)255u);
+    for (int ord = 0; ord < n_ord; ord++) fill_lds_image(s, img + ord * s->lds_image_bytes, ord);
+  }
+}
+
+// what of a resident scene depends on the camera and is decided on the host: is it a strict-kernel scene, which sphere encloses
+// everything, the background constant, the cull rectangles and cost weights of the launch tables
+void camera_decisions(rt_scene_dev *s) {
+  const rt_scene_header *hd = &s->hd;
+  const rt_sphere *ob = (const rt_sphere *)(s->host_blob.data() + hd->objects_offset);
+  s->needs_strict = s->needs_strict_scene;
+  for (int c = 0; c < 3; c++) if (hd->cam_axis_x[c] + hd->cam_axis_y[c] + hd->cam_axis_z[c] == 0.0) s->needs_strict = true;
+  // cost-ordered dispatch: what a tile that shows sphere j is expected to cost, in rough units of one shaded hit - a guess
+  // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
+  // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
+  scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
+}
+
+// a staging slot of `bytes` (<= stage_bytes), free to be written: its previous copy has been read
+uint8_t *acquire_stage(rt_scene_dev *s, rt_scene_dev::stage_slot **slot) {
+  rt_scene_dev::stage_slot &g = s->stages[s->stage_next++ & 3u];
+  if (g.used) (void)hipEventSynchronize(g.done);
+  g.used = true;
+  *slot = &g;
+  return g.h;
+}
+}  // namespace
+
 extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
   if (!out) return fail(RT_ERR_INVALID, "out handle is NULL");
   *out = nullptr;
@@ -269,6 +380,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
   s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr; s->d_shadow_grid = nullptr; s->d_bounce_table = nullptr;
+  s->d_cam = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -280,18 +392,17 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   //   * a sphere with r2 <= 0 or not finite (no 1/r);
   //   * a sphere-checker whose frequencies are negative, NaN or >= 2^31 (below);
   //   * a camera whose axis sums (main.js:187-191, quirk q1) have an exactly zero component: EVERY primary ray then lies in
-  //     a coordinate plane through the camera (rt_kernel.hip marks the centre row / column of an odd sample grid for the same reason).
-  s->needs_strict = false;
-  for (int c = 0; c < 3; c++) if (hd->cam_axis_x[c] + hd->cam_axis_y[c] + hd->cam_axis_z[c] == 0.0) s->needs_strict = true;
+  //     a coordinate plane through the camera (camera_decisions; rt_retrace traces the centre row / column of an odd sample grid
+  //     for the same reason).
+  s->needs_strict_scene = false;
   for (uint32_t i = 0; i < hd->n_objects; i++) {
-    if (!(ob[i].r2 > 0.0) || !std::isfinite(ob[i].r2)) s->needs_strict = true;
+    if (!(ob[i].r2 > 0.0) || !std::isfinite(ob[i].r2)) s->needs_strict_scene = true;
     const double *lt = (const double *)(base + hd->lights_offset);
     for (uint32_t k = 0; k < hd->n_lights; k++) {
       const double x = lt[3 * k] - ob[i].origin[0], y = lt[3 * k + 1] - ob[i].origin[1], z = lt[3 * k + 2] - ob[i].origin[2];
-      if (fabs((x * x + y * y + z * z) - ob[i].r2) <= 1e-9 * fmax(ob[i].r2, 1.0)) s->needs_strict = true;
+      if (fabs((x * x + y * y + z * z) - ob[i].r2) <= 1e-9 * fmax(ob[i].r2, 1.0)) s->needs_strict_scene = true;
     }
   }
-
   // the boundary test of the product kernel's samplers (rt_device.h: RT_FLAG_T1): a coordinate is u * frequency
   {
     double fmaxq = 1.0;
@@ -305,14 +416,14 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
         if (fabs(f1) > fmaxq) fmaxq = fabs(f1);
         // the product kernel takes ToInt32(u * f) & 1 (main.js:129-130) from a fixed-point sum that holds it for products in [0, 2^31):
         // other frequencies (negative, huge, NaN) make the scene a strict-kernel scene
-        if (!(f0 >= 0.0 && f0 < 2147483648.0 && f1 >= 0.0 && f1 < 2147483648.0)) s->needs_strict = true;
+        if (!(f0 >= 0.0 && f0 < 2147483648.0 && f1 >= 0.0 && f1 < 2147483648.0)) s->needs_strict_scene = true;
       }
     }
     s->flag_tol = RT_FLAG_T1 * fmaxq;
   }
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
-  rt_texture_desc descs[RT_MAX_TEXTURES];
+  rt_texture_desc (&descs)[RT_MAX_TEXTURES] = s->descs;
   memset(descs, 0, sizeof descs);
   if (hd->n_textures) memcpy(descs, base + hd->textures_offset, hd->n_textures * sizeof(rt_texture_desc));
   s->enclosing = enclosing_sphere(hd, ob, s->lights);     // (rt_tables.cpp)
@@ -334,117 +445,117 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
       s->sky_rgb[c] = (m1 < amb) ? (double)amb : m1;                    // Math.max(amb, .) as the kernel's maxa() evaluates it
     }
   }
-  // cost-ordered dispatch: what a tile that shows sphere j is expected to cost, in rough units of one shaded hit - a guess
-  // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
-  // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
-  scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
   s->host_objects.assign(ob, ob + hd->n_objects);
   // device copy of the blob: the `reserved` slot of each sphere record carries 1/r for the product kernel
-  std::vector<uint8_t> patched((const uint8_t *)blob, (const uint8_t *)blob + bytes);
+  s->host_blob.assign((const uint8_t *)blob, (const uint8_t *)blob + bytes);
   {
-    rt_sphere *pob = (rt_sphere *)(patched.data() + hd->objects_offset);
+    rt_sphere *pob = (rt_sphere *)(s->host_blob.data() + hd->objects_offset);
     for (uint32_t i = 0; i < hd->n_objects; i++) pob[i].reserved = 1.0 / sqrt(pob[i].r2);
   }
-  // Geometry tables (32-byte records), per ordering: [0,N) plain {origin, r2}; [N,2N) anchored at the camera
-  // {o - cam, |o - cam|^2 - r2}; [2N,3N) primary-ray cull rectangles; [3N, 3N + NL*N) anchored at each light.  Ordering A = the scene's own order
-  // (strict kernel, counting variant).  Ordering B = the enclosing sphere moved to the end, so the product
-  // kernel's loops run over [0, N-1) and never test it.
-  const uint32_t NO = hd->n_objects;
-  const size_t per_order = (size_t)NO * (3 + hd->n_lights);
-  const bool has_b = s->enclosing != ~0u;
-  std::vector<rt_geom> geom(per_order * (has_b ? 2 : 1));
-  std::vector<rt_sphere> objs_b;
+  camera_decisions(s);
+  // Two orderings of the spheres.  A = the scene's own order (strict kernels, counting variant).  B = the enclosing sphere moved to
+  // the end, so that the product kernel's loops run over [0, N-1) and never test it.
+  const uint32_t NO = hd->n_objects, NL = hd->n_lights;
+  s->has_b = s->enclosing != ~0u;
+  const bool has_b = s->has_b;
+  const int n_ord = has_b ? 2 : 1;
+  const rt_sphere *pob_a = (const rt_sphere *)(s->host_blob.data() + hd->objects_offset);
+  s->host_objects_b.clear();
+  if (has_b) {
+    for (uint32_t i = 0; i < NO; i++) if (i != s->enclosing) s->host_objects_b.push_back(pob_a[i]);
+    s->host_objects_b.push_back(pob_a[s->enclosing]);
+  }
+  const uint32_t n_loop_b = has_b ? NO - 1 : NO;       // spheres in the product kernel's loops
+  static const uint32_t sgrid_min = RT_TEST_ENV("RT_SGRID_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;     // A/B switches (test build)
+  static const uint32_t btable_min = RT_TEST_ENV("RT_BTABLE_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;
+  const bool want_shadow_grid = n_loop_b > sgrid_min && NL > 0;
+  const bool want_bounce_table = n_loop_b > btable_min && hd->segs > 1;      // rays bounce at all only from depth 2 on
+  // few spheres: the cull rectangles ride in the LDS image; scenes that get a shadow grid or a bounce table run the many-sphere
+  // kernel variant, which fetches them per lane (rt_kernel.hip: 64 spheres + the fold state then fit 32 KB of LDS, five workgroups
+  // per CU instead of four)
+  s->cull_in_lds = !(want_shadow_grid || want_bounce_table);
+  s->lds_image_bytes = (size_t)NO * (sizeof(rt_mtl) + (s->cull_in_lds ? sizeof(rt_geom) : 0u)) + sizeof descs;
+  s->lds_bytes = (unsigned)s->lds_image_bytes;
+  std::vector<uint64_t> sg, bt;
+  if (want_shadow_grid) sg = build_shadow_grid(has_b ? s->host_objects_b.data() : pob_a, n_loop_b, NL, s->lights);
+  if (want_bounce_table) bt = build_bounce_table(has_b ? s->host_objects_b.data() : pob_a, NO, n_loop_b);
+  // ---- the arena's layout (every part 256-byte aligned) ----
+  auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+  size_t at = 0;
+  const size_t off_blob = at; at = up(at + bytes);
+  const size_t off_tex = at; at = up(at + sizeof descs);
+  const size_t geom_per_order = (size_t)NO * (1 + NL);                 // [plain N | anchored at light k: NL x N]
+  const size_t off_geom = at; at = up(at + (geom_per_order * n_ord + 1) * sizeof(rt_geom));   // + one record of padding: the kernel's scans fetch a light's first two records at once, also when it has one
+  const size_t off_objs_b = at; at = up(at + (has_b ? NO * sizeof(rt_sphere) : 0));
+  const size_t off_img = at; at = up(at + (s->cull_in_lds ? 0 : s->lds_image_bytes * n_ord + 4096u));   // the many-sphere kernel reads whole 4 KB pieces (rt_kernel.hip staging)
+  const size_t off_sg = at; at = up(at + sg.size() * sizeof(uint64_t));
+  const size_t off_bt = at; at = up(at + bt.size() * sizeof(uint64_t));
+  const size_t off_cam = at;
+  s->cam_bytes = up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) + (s->cull_in_lds ? s->lds_image_bytes * n_ord + 4096u : 0);
+  at = up(at + s->cam_bytes);
+  s->arena_bytes = at;
+  std::vector<uint8_t> host(at, 0);
+  memcpy(host.data() + off_blob, s->host_blob.data(), bytes);
+  memcpy(host.data() + off_tex, descs, sizeof descs);
   auto anchored = [&](const rt_sphere &o, const double a[3]) {
     const double lx = o.origin[0] - a[0], ly = o.origin[1] - a[1], lz = o.origin[2] - a[2];
     return rt_geom{lx, ly, lz, (lx * lx + ly * ly + lz * lz) - o.r2};
   };
-  auto fill = [&](const rt_sphere *src, rt_geom *dst) {
+  for (int ord = 0; ord < n_ord; ord++) {
+    const rt_sphere *src = ord ? s->host_objects_b.data() : pob_a;
+    rt_geom *dst = (rt_geom *)(host.data() + off_geom) + ord * geom_per_order;
     for (uint32_t i = 0; i < NO; i++) {
       dst[i] = rt_geom{src[i].origin[0], src[i].origin[1], src[i].origin[2], src[i].r2};
-      dst[NO + i] = anchored(src[i], hd->cam_origin);
-      dst[2 * (size_t)NO + i] = cull_rect(hd, src[i]);
-      for (uint32_t k = 0; k < hd->n_lights; k++) dst[(size_t)NO * (3 + k) + i] = anchored(src[i], s->lights[k]);
+      for (uint32_t k = 0; k < NL; k++) dst[(size_t)NO * (1 + k) + i] = anchored(src[i], s->lights[k]);
     }
+  }
+  ((rt_geom *)(host.data() + off_geom))[geom_per_order * n_ord] = rt_geom{0.0, 0.0, 0.0, -1.0};
+  if (has_b) memcpy(host.data() + off_objs_b, s->host_objects_b.data(), NO * sizeof(rt_sphere));
+  if (!sg.empty()) memcpy(host.data() + off_sg, sg.data(), sg.size() * sizeof(uint64_t));
+  if (!bt.empty()) memcpy(host.data() + off_bt, bt.data(), bt.size() * sizeof(uint64_t));
+  // the LDS images' camera-independent part: [materials | texture descriptors]
+  auto fill_image = [&](uint8_t *dst, const rt_sphere *src) {
+    rt_mtl *mt = (rt_mtl *)dst;
+    for (uint32_t i = 0; i < NO; i++) {
+      const rt_sphere &o = src[i];
+      rt_mtl &m = mt[i];
+      memset(&m, 0, sizeof m);
+      memcpy(m.origin, o.origin, sizeof m.origin);
+      m.inv_r = o.reserved;                           // 1/r, patched above
+      memcpy(m.albedo, o.albedo, sizeof m.albedo);
+      m.specular_exponent = o.specular_exponent; m.refract_index = o.refract_index;
+      m.sampler_kind = o.sampler_kind; m.texture = o.texture;
+      if (o.sampler_kind == RT_SAMPLER_CHECKER) memcpy(m.c, o.checker_color, 6 * sizeof(double));
+      else memcpy(m.c, o.color, 3 * sizeof(double));
+      m.c[6] = o.checker_freq[0]; m.c[7] = o.checker_freq[1];
+    }
+    memcpy(dst + (size_t)NO * sizeof(rt_mtl), descs, sizeof descs);
   };
-  const rt_sphere *pob_a = (const rt_sphere *)(patched.data() + hd->objects_offset);
-  fill(pob_a, geom.data());
-  if (has_b) {
-    for (uint32_t i = 0; i < NO; i++) if (i != s->enclosing) objs_b.push_back(pob_a[i]);
-    objs_b.push_back(pob_a[s->enclosing]);
-    fill(objs_b.data(), geom.data() + per_order);
+  uint8_t *img_host = host.data() + (s->cull_in_lds ? off_cam + up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) : off_img);
+  for (int ord = 0; ord < n_ord; ord++) fill_image(img_host + ord * s->lds_image_bytes, ord ? s->host_objects_b.data() : pob_a);
+  fill_camera_block(s, host.data() + off_cam);
+  // ---- one allocation, one copy ----
+  hipError_t e = hipMalloc((void **)&s->arena, s->arena_bytes);
+  if (e == hipSuccess) e = hipMemcpy(s->arena, host.data(), s->arena_bytes, hipMemcpyHostToDevice);
+  // pinned staging for what follows a camera move
+  s->stage_bytes = s->cam_bytes > 65536u ? s->cam_bytes : 65536u;
+  for (rt_scene_dev::stage_slot &g : s->stages) {
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g.h, s->stage_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
   }
-  hipError_t e = hipMalloc(&s->d_blob, bytes);
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_texdesc, sizeof descs);
-  geom.push_back(rt_geom{0.0, 0.0, 0.0, -1.0});        // one record of padding: the kernel's scans fetch a light's first two records at once, also when it has one
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_geom, geom.size() * sizeof(rt_geom));
-  if (e == hipSuccess) e = hipMemcpy(s->d_geom, geom.data(), geom.size() * sizeof(rt_geom), hipMemcpyHostToDevice);
-  const uint32_t n_loop_b = has_b ? NO - 1 : NO;       // spheres in the product kernel's loops
-  static const uint32_t sgrid_min = RT_TEST_ENV("RT_SGRID_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_SGRID_MIN")) : RT_SGRID_MIN_LOOP;     // A/B switches (test build)
-  static const uint32_t btable_min = RT_TEST_ENV("RT_BTABLE_MIN") ? (uint32_t)atoi(RT_TEST_ENV("RT_BTABLE_MIN")) : RT_BTABLE_MIN_LOOP;
-  const bool want_shadow_grid = n_loop_b > sgrid_min && hd->n_lights > 0;
-  const bool want_bounce_table = n_loop_b > btable_min && hd->segs > 1;      // rays bounce at all only from depth 2 on
-  {
-    // the LDS image, per ordering
-    // few spheres: the cull rectangles ride in the image as well; scenes that get a shadow grid or a bounce table (below) run the
-    // many-sphere kernel variant, which fetches them per lane (rt_kernel.hip: 64 spheres + the fold state then fit 32 KB of LDS,
-    // five workgroups per CU instead of four)
-    s->cull_in_lds = !(want_shadow_grid || want_bounce_table);
-    s->lds_image_bytes = (size_t)NO * (sizeof(rt_mtl) + (s->cull_in_lds ? sizeof(rt_geom) : 0u)) + sizeof descs;
-    s->lds_bytes = (unsigned)s->lds_image_bytes;
-    std::vector<uint8_t> img(s->lds_image_bytes * (has_b ? 2 : 1));
-    for (int ord = 0; ord < (has_b ? 2 : 1); ord++) {
-      uint8_t *dst = img.data() + ord * s->lds_image_bytes;
-      const rt_sphere *src = ord ? objs_b.data() : pob_a;
-      rt_mtl *mt = (rt_mtl *)dst;
-      for (uint32_t i = 0; i < NO; i++) {
-        const rt_sphere &o = src[i];
-        rt_mtl &m = mt[i];
-        memset(&m, 0, sizeof m);
-        memcpy(m.origin, o.origin, sizeof m.origin);
-        m.inv_r = o.reserved;                           // 1/r, patched above
-        memcpy(m.albedo, o.albedo, sizeof m.albedo);
-        m.specular_exponent = o.specular_exponent; m.refract_index = o.refract_index;
-        m.sampler_kind = o.sampler_kind; m.texture = o.texture;
-        if (o.sampler_kind == RT_SAMPLER_CHECKER) memcpy(m.c, o.checker_color, 6 * sizeof(double));
-        else memcpy(m.c, o.color, 3 * sizeof(double));
-        m.c[6] = o.checker_freq[0]; m.c[7] = o.checker_freq[1];
-      }
-      memcpy(dst + (size_t)NO * sizeof(rt_mtl), descs, sizeof descs);
-      if (s->cull_in_lds) memcpy(dst + (size_t)NO * sizeof(rt_mtl) + sizeof descs, geom.data() + ord * per_order + 2 * (size_t)NO, (size_t)NO * sizeof(rt_geom));
-    }
-    img.resize(img.size() + 4096u, 0);               // the many-sphere kernel reads whole 4 KB pieces (rt_kernel.hip staging)
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_lds_image, img.size());
-    if (e == hipSuccess) e = hipMemcpy(s->d_lds_image, img.data(), img.size(), hipMemcpyHostToDevice);
-  }
-  {
-    // shadow grids, in the loop order the product kernel uses (B when there is an enclosing sphere)
-    const uint32_t n_loop = n_loop_b;
-    if (want_shadow_grid) {
-      const std::vector<uint64_t> sg = build_shadow_grid(has_b ? objs_b.data() : pob_a, n_loop, hd->n_lights, s->lights);
-      if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_grid, sg.size() * sizeof(uint64_t));
-      if (e == hipSuccess) e = hipMemcpy(s->d_shadow_grid, sg.data(), sg.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-    }
-    if (want_bounce_table) {
-      const std::vector<uint64_t> bt = build_bounce_table(has_b ? objs_b.data() : pob_a, NO, n_loop);
-      if (e == hipSuccess) e = hipMalloc((void **)&s->d_bounce_table, bt.size() * sizeof(uint64_t));
-      if (e == hipSuccess) e = hipMemcpy(s->d_bounce_table, bt.data(), bt.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-    }
-  }
-  if (e == hipSuccess && has_b) e = hipMalloc((void **)&s->d_objects_b, objs_b.size() * sizeof(rt_sphere));
-  if (e == hipSuccess && has_b) e = hipMemcpy(s->d_objects_b, objs_b.data(), objs_b.size() * sizeof(rt_sphere), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(s->d_blob, patched.data(), bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(s->d_texdesc, descs, sizeof descs, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    if (s->d_blob) (void)hipFree(s->d_blob);
-    if (s->d_texdesc) (void)hipFree(s->d_texdesc);
-    if (s->d_geom) (void)hipFree(s->d_geom);
-    if (s->d_objects_b) (void)hipFree(s->d_objects_b);
-    if (s->d_lds_image) (void)hipFree(s->d_lds_image);
-    if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
-    if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
-    delete s;
-    return fail(RT_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
+    const std::string why = hipGetErrorString(e);
+    rt_scene_free(s);
+    return fail(RT_ERR_DEVICE, "scene upload: %s", why.c_str());
   }
+  s->d_blob = s->arena + off_blob;
+  s->d_texdesc = (rt_texture_desc *)(s->arena + off_tex);
+  s->d_geom = (rt_geom *)(s->arena + off_geom);
+  s->d_objects_b = has_b ? (rt_sphere *)(s->arena + off_objs_b) : nullptr;
+  s->d_shadow_grid = sg.empty() ? nullptr : (uint64_t *)(s->arena + off_sg);
+  s->d_bounce_table = bt.empty() ? nullptr : (uint64_t *)(s->arena + off_bt);
+  s->d_cam = s->arena + off_cam;
+  s->d_lds_image = s->cull_in_lds ? s->d_cam + up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) : s->arena + off_img;
   *out = s;
   return RT_OK;
 }
@@ -452,17 +563,48 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
 extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (!s) return;
   if (G.inited && s->device < (int)G.dev.size()) (void)hipSetDevice(G.dev[s->device].hip_id);
-  (void)hipFree(s->d_blob);
-  (void)hipFree(s->d_texdesc);
-  (void)hipFree(s->d_geom);
-  if (s->d_objects_b) (void)hipFree(s->d_objects_b);
-  if (s->d_lds_image) (void)hipFree(s->d_lds_image);
-  if (s->d_shadow_grid) (void)hipFree(s->d_shadow_grid);
-  if (s->d_bounce_table) (void)hipFree(s->d_bounce_table);
-  for (const rt_scene_dev::order_entry &e : s->orders) (void)hipFree(e.d_order);
+  (void)hipDeviceSynchronize();                    // nothing of this scene is in flight any more
+  if (s->arena) (void)hipFree(s->arena);
+  for (rt_scene_dev::stage_slot &g : s->stages) { if (g.h) (void)hipHostFree(g.h); if (g.done) (void)hipEventDestroy(g.done); }
+  if (s->cam_ready) (void)hipEventDestroy(s->cam_ready);
+  for (rt_scene_dev::order_entry &e : s->orders) free_order_entry(e);
   for (const rt_scene_dev::mark_state &m : s->mark_states) (void)hipFree(m.d_marks);
   if (s->h_known_pool) (void)hipHostFree(s->h_known_pool);
   delete s;
+}
+
+// The camera of a resident scene moves (lookAt, main.js:92-100; the reference recomputes everything per redraw, main.js:180-201).
+// What depends on it - the camera-anchored geometry, the cull rectangles, the LDS images that hold them - is ONE block of the
+// scene's arena, rewritten here with one small asynchronous copy on `hip_stream`; the launch tables of the scene are rebuilt on
+// the GPU by the next launch that needs them (dispatch_order).  Nothing waits for the GPU unless launches of this scene are in
+// flight on ANOTHER stream (then the device is drained first: they may still read the old block).
+extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], const double axis_x[3], const double axis_y[3], const double axis_z[3], void *hip_stream) {
+  if (!s || !origin || !axis_x || !axis_y || !axis_z) return fail(RT_ERR_INVALID, "rt_scene_set_camera: NULL argument");
+  int rc = ensure_device(s->device);
+  if (rc) return rc;
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[s->device].stream;
+  std::lock_guard<std::mutex> lk(s->launch_mu);
+  rt_scene_header nh = s->hd;
+  memcpy(nh.cam_origin, origin, 24); memcpy(nh.cam_axis_x, axis_x, 24); memcpy(nh.cam_axis_y, axis_y, 24); memcpy(nh.cam_axis_z, axis_z, 24);
+  if (memcmp(&nh, &s->hd, sizeof nh) == 0) return RT_OK;
+  // the two orderings of the scene's tables are built around the sphere that encloses everything INCLUDING the camera
+  if (enclosing_sphere(&nh, s->host_objects.data(), s->lights) != s->enclosing)
+    return fail(RT_ERR_UNSUPPORTED, "rt_scene_set_camera: the camera crossed the enclosing sphere (the scene's tables are laid out around it): upload the scene again");
+  if (s->any_launch && (s->several_streams || s->last_stream != stream)) HIP_TRY(hipDeviceSynchronize());
+  s->hd = nh;
+  memcpy(s->host_blob.data(), &nh, sizeof nh);
+  camera_decisions(s);
+  s->cam_gen++;
+  rt_scene_dev::stage_slot *slot = nullptr;
+  uint8_t *st = acquire_stage(s, &slot);
+  fill_camera_block(s, st);
+  HIP_TRY((hipError_t)rt_launch_small_copy(s->d_cam, st, s->cam_bytes, stream));            // (a one-workgroup kernel that reads the pinned slot)
+  HIP_TRY(hipEventRecord(slot->done, stream));
+  if (!s->cam_ready) HIP_TRY(hipEventCreateWithFlags(&s->cam_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(s->cam_ready, stream));
+  s->cam_stream = stream;
+  s->any_launch = false; s->several_streams = false;
+  return RT_OK;
 }
 
 // ------------------------------------------------------------------------------------ launch
@@ -522,44 +664,155 @@ extern "C" int rt_render_scatter_device(rt_scene_dev *s, uint32_t w, uint32_t h,
 }
 
 namespace {
-const void *dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                           double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t *n_entries, bool *temporary,
-                           uint32_t *order_index) {
-  *temporary = false;
-  *order_index = ~0u;
-  std::lock_guard<std::mutex> lk(s->order_mu);
+// a pinned host word of the scene's pool (generation << 32 | value + 1, written by a kernel): [0, RT_KNOWN_WORDS) the mark states',
+// [RT_KNOWN_WORDS, 2 RT_KNOWN_WORDS) the launch tables'
+volatile unsigned long long *known_word(rt_scene_dev *s, size_t index) {
+  if (!s->h_known_pool) {
+    if (hipHostMalloc((void **)&s->h_known_pool, 2 * RT_KNOWN_WORDS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s->h_known_pool = nullptr; return nullptr; }
+    memset(s->h_known_pool, 0, 2 * RT_KNOWN_WORDS * sizeof(unsigned long long));
+  }
+  return index < 2 * RT_KNOWN_WORDS ? s->h_known_pool + index : nullptr;
+}
+// what a kernel published for camera generation `gen`: value + 1, or 0 (nothing yet, or an older camera's)
+uint32_t known_value(const volatile unsigned long long *p, uint64_t gen) {
+  if (!p) return 0u;
+  const unsigned long long v = *p;
+  return (uint32_t)(v >> 32) == (uint32_t)gen ? (uint32_t)v : 0u;
+}
+
+// The launch table of this (frame size, tile set, flags) for the scene's CURRENT camera: found, or built on the GPU - three small
+// launches on `stream` (rt_tables_gpu.hip), behind one small copy of its parameters; nothing waits for them.  Called with the
+// scene's launch_mu held.  Returns the entry's index, or -1 (rt_last_error says why).
+int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
+                   double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, hipStream_t stream) {
+  int found = -1;
   for (size_t i = 0; i < s->orders.size(); i++) {
     const rt_scene_dev::order_entry &e = s->orders[i];
     if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
-        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates) {
-      *n_entries = e.n_entries;
-      *order_index = (uint32_t)i;
-      return e.d_order;
-    }
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates) { found = (int)i; break; }
   }
-  const std::vector<uint32_t> table = build_launch_table(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile,
-                                                         proj_w, proj_h, proj_d, ranked, mark_sky, s->enclosing, shadow_masks, name_candidates, s->lights, n_entries);
-  if (table.empty()) { fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile); return nullptr; }
-  uint32_t *d = nullptr;
-  hipError_t e = hipMalloc((void **)&d, table.size() * 4u);
-  if (e == hipSuccess) e = hipMemcpy(d, table.data(), table.size() * 4u, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { if (d) (void)hipFree(d); fail(RT_ERR_DEVICE, "launch table: %s", hipGetErrorString(e)); return nullptr; }
-  // A cached table is never freed while the scene lives (another thread may be about to launch with it); a scene that has
-  // been rendered with 64 different (frame size, tile set) pairs gets per-call tables from then on, freed by the caller once
-  // its launches have drained.
-  if (s->orders.size() >= 64u) { *temporary = true; return d; }
-  s->orders.push_back({w, h, ss, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, ranked, mark_sky, shadow_masks, name_candidates, *n_entries, d});
-  *order_index = (uint32_t)(s->orders.size() - 1u);
-  return d;
+  if (found >= 0 && s->orders[found].cam_gen == s->cam_gen) {
+    rt_scene_dev::order_entry &e = s->orders[found];
+    // built on another stream: this stream's launches come behind the build
+    if (e.built_on != stream) { if (hipStreamWaitEvent(stream, e.built, 0) != hipSuccess) { fail(RT_ERR_DEVICE, "launch table: hipStreamWaitEvent"); return -1; } e.shared = true; }
+    return found;
+  }
+  rt_table_params P;
+  std::vector<rt_ball> balls;
+  std::vector<rt_cost_rect> rects;
+  if (make_table_params(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, ranked, mark_sky,
+                        s->enclosing, shadow_masks, name_candidates, s->lights, &P, &balls, &rects)) {
+    fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile);
+    return -1;
+  }
+  const uint32_t n = P.tiles_x * P.ny;
+  const size_t hist_words = (size_t)P.ny * P.cost_bins;
+  if (found < 0) {
+    // a scene that has been rendered with 64 different (frame size, tile set) pairs gives up its oldest table (nothing of it may be
+    // in flight: the device is drained first; rare)
+    if (s->orders.size() >= 64u) {
+      (void)hipDeviceSynchronize();
+      free_order_entry(s->orders[s->order_evict % 64u]);
+      found = (int)(s->order_evict++ % 64u);
+      for (rt_scene_dev::mark_state &m : s->mark_states) if (m.order_index == (uint32_t)found && m.h_known) *m.h_known = 0ull;     // its mark counts were another table's
+    } else {
+      s->orders.push_back(rt_scene_dev::order_entry());
+      found = (int)s->orders.size() - 1;
+    }
+    rt_scene_dev::order_entry &e = s->orders[found];
+    memset(&e, 0, sizeof e);
+    e.w = w; e.h = h; e.ss = ss; e.tile_rows = tiles->tile_rows; e.tile_first = tiles->tile_first; e.tile_stride = tiles->tile_stride; e.n_tiles = tiles->n_tiles;
+    e.ranked = ranked; e.sky = mark_sky; e.masks = shadow_masks; e.cands = name_candidates;
+    e.known = known_word(s, RT_KNOWN_WORDS + (size_t)found);
+    if (e.known) *e.known = 0ull;                        // (a table evicted from this slot may have published its count for the same camera)
+  }
+  rt_scene_dev::order_entry &e = s->orders[found];
+  // the table's device memory: one allocation behind all its arrays; the per-row histograms grow with the camera's cost range
+  if (!e.d_block || e.hist_words < hist_words) {
+    if (e.d_block) { (void)hipDeviceSynchronize(); (void)hipFree(e.d_block); e.d_block = nullptr; }
+    auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+    const size_t cap_hist = hist_words > (size_t)P.ny * 128u ? hist_words : (size_t)P.ny * 128u;
+    const size_t dyn_bytes = up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_cost_rect));
+    size_t at = 0;
+    const size_t o_dyn = at; at += dyn_bytes;
+    const size_t o_blk = at; at = up(at + (size_t)n * 12u);
+    const size_t o_item = at; at = up(at + (size_t)n * 4u);
+    const size_t o_rank = at; at = up(at + (size_t)n * 4u);
+    const size_t o_hist = at; at = up(at + cap_hist * 4u);
+    const size_t o_bins = at; at = up(at + (size_t)(RT_COST_MAX + 1u) * 4u);
+    const size_t o_head = at; at = up(at + 16u + ((size_t)(n + 7u) / 8u) * 8u * 16u);
+    hipError_t er = hipMalloc((void **)&e.d_block, at);
+    if (er == hipSuccess && !e.built) er = hipEventCreateWithFlags(&e.built, hipEventDisableTiming);
+    if (er != hipSuccess) { fail(RT_ERR_DEVICE, "launch table (%zu bytes): %s", at, hipGetErrorString(er)); return -1; }
+    e.hist_words = cap_hist;
+    e.T.params = (const rt_table_params *)(e.d_block + o_dyn);
+    e.T.balls = (const rt_ball *)(e.d_block + o_dyn + up(sizeof(rt_table_params)));
+    e.T.rects = (const rt_cost_rect *)(e.d_block + o_dyn + up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)));
+    e.T.blk = (uint32_t *)(e.d_block + o_blk); e.T.item = (uint32_t *)(e.d_block + o_item); e.T.rank_in_row = (uint32_t *)(e.d_block + o_rank);
+    e.T.row_hist = (uint32_t *)(e.d_block + o_hist); e.T.bin_start = (uint32_t *)(e.d_block + o_bins);
+    e.T.header = (uint32_t *)(e.d_block + o_head); e.T.entries = e.T.header + 4;
+    e.T.known = (unsigned long long *)e.known;
+  } else if (e.shared || e.built_on != stream) {
+    (void)hipDeviceSynchronize();                        // the old table may still be read on another stream: rebuilt only when nothing is in flight (rare)
+  }
+  e.n_blocks = n;
+  e.cam_gen = s->cam_gen;
+  e.T.known_tag = (uint32_t)s->cam_gen;
+  e.built_on = stream; e.shared = false;
+  // parameters, cone-test spheres and cost rectangles: one staging slot, one asynchronous copy
+  auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+  rt_scene_dev::stage_slot *slot = nullptr;
+  uint8_t *st = acquire_stage(s, &slot);
+  const size_t o_balls = up(sizeof(rt_table_params)), o_rects = o_balls + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball));
+  const size_t copy_bytes = o_rects + rects.size() * sizeof(rt_cost_rect);
+  memcpy(st, &P, sizeof P);
+  if (!balls.empty()) memcpy(st + o_balls, balls.data(), balls.size() * sizeof(rt_ball));
+  if (!rects.empty()) memcpy(st + o_rects, rects.data(), rects.size() * sizeof(rt_cost_rect));
+  // (copied by a one-workgroup kernel that reads the pinned slot: an SDMA copy in front of the build costs two engine hand-overs)
+  hipError_t er = (hipError_t)rt_launch_small_copy((void *)e.T.params, st, copy_bytes, stream);
+  if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
+  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, stream);
+  if (er == hipSuccess) er = hipEventRecord(e.built, stream);
+  if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return -1; }
+  return found;
 }
 
 }  // namespace
 
-// Host-logic probe (no GPU): the product kernel's launch table for `tiles` of the w x h frame, exactly as render_batch_impl
-// builds it: out_entries receives 4 words per entry, 8 * ceil(n / 8) entries with workgroup b's entry at (b % 8) * ceil(n / 8)
-// + b / 8; *n_workgroups = n.  Pass out_entries = NULL to ask for n only.
+#ifdef RT_TESTING
+// Test build only: the launch table as the library builds it ON THE GPU for `tiles` of the w x h frame of a resident scene (its
+// current camera), read back: same arguments and layout as the host-logic probe rt_scene_launch_table below, whose table (the host
+// build of the same rt_block.h) it must equal word for word.
+extern "C" int rt_test_launch_table(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked, uint32_t *out_entries, uint32_t *n_workgroups, uint32_t *n_blocks) {
+  if (!s || !tiles || !n_workgroups) return fail(RT_ERR_INVALID, "rt_test_launch_table: NULL argument");
+  int rc = ensure_device(s->device);
+  if (rc) return rc;
+  hipStream_t stream = G.dev[s->device].stream;
+  const uint32_t ss = s->hd.supersample, rows_per_wg = ss == 2u ? 2u : RT_TILE_H;
+  if (ss > 2u) return fail(RT_ERR_INVALID, "supersample 3 and 4 launch on the sample grid");
+  const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
+  const double pw = (double)w * ss / 2.0, ph = (double)h * ss / 2.0, pd = pw / tan(s->hd.fov_deg * M_PI / 180.0 / 2.0);
+  std::lock_guard<std::mutex> lk(s->launch_mu);
+  const int oi = dispatch_order(s, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, (ranked & 4) != 0, (ranked & 4) != 0, stream);
+  if (oi < 0) return RT_ERR_DEVICE;
+  HIP_TRY(hipStreamSynchronize(stream));
+  const rt_scene_dev::order_entry &e = s->orders[oi];
+  uint32_t header[4];
+  HIP_TRY(hipMemcpy(header, e.T.header, sizeof header, hipMemcpyDeviceToHost));
+  if (known_value(e.known, s->cam_gen) != header[0] + 1u) return fail(RT_ERR_STATE, "the build published %u entries to the host, its header says %u", known_value(e.known, s->cam_gen), header[0] + 1u);
+  *n_workgroups = header[0];
+  if (n_blocks) *n_blocks = e.n_blocks;
+  if (out_entries) HIP_TRY(hipMemcpy(out_entries, e.T.entries, (size_t)((e.n_blocks + 7u) / 8u) * 8u * 16u, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+#endif
+
+// Host-logic probe (no GPU): the product kernel's launch table for `tiles` of the w x h frame as the HOST builds it (rt_tables.cpp;
+// the library builds the same table on the GPU, rt_tables_gpu.hip): out_entries receives 4 words per slot, 8 * ceil(blocks / 8) slots
+// with workgroup b's entry in slot (b % 8) * ceil(blocks / 8) + b / 8; *n_workgroups = the number of entries, *n_blocks = the number
+// of blocks.  Pass out_entries = NULL to ask for the two numbers only.
 extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
-                                     uint32_t *out_entries, uint32_t *n_workgroups) {
+                                     uint32_t *out_entries, uint32_t *n_workgroups, uint32_t *n_blocks) {
   int rc = rt_scene_validate(blob, bytes);
   if (rc) return rc;
   if (!tiles || !n_workgroups || w == 0 || h == 0 || w > 65536 || h > 65536 || tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0)
@@ -584,6 +837,7 @@ extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w,
                                                          (ranked & 4) != 0, (ranked & 4) != 0, lights, &n_entries);
   if (table.empty()) return fail(RT_ERR_INVALID, "a launch of this size is beyond the launch table");
   *n_workgroups = n_entries;
+  if (n_blocks) *n_blocks = tiles_x * tiles->n_tiles * rb_per_tile;
   if (out_entries) memcpy(out_entries, table.data(), table.size() * sizeof(uint32_t));
   return RT_OK;
 }
@@ -714,6 +968,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   device_state &D = G.dev[s->device];
   hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : D.stream;
   const auto t_begin = std::chrono::steady_clock::now();
+  {
+    // which streams the scene's launches run on (rt_scene_set_camera, dispatch_order), and: behind the last write of the camera block
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    if (s->cam_ready && s->cam_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->cam_ready, 0));
+    if (s->any_launch && s->last_stream != stream) s->several_streams = true;
+    s->last_stream = stream; s->any_launch = true;
+  }
 
   const rt_scene_header &hd = s->hd;
   const uint32_t ss = ss_override ? ss_override : hd.supersample;
@@ -738,12 +999,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   auto bind_kernel = [&](rt_launch &K, bool strict) {
     const bool plain = strict || count;
     const bool order_b = s->d_objects_b && !plain;
-    const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (3 + hd.n_lights) : 0);
+    const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (1 + hd.n_lights) : 0);      // [plain N | anchored at light k: NL x N]
+    const rt_geom *gc = (const rt_geom *)s->d_cam + (order_b ? 2 * (size_t)hd.n_objects : 0);          // camera block: [anchored at the camera N | cull rectangles N]
     K.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
     K.geom = gt;
-    K.geom_cam = gt + hd.n_objects;
-    K.cull = gt + 2 * (size_t)hd.n_objects;
-    K.geom_light = gt + 3 * (size_t)hd.n_objects;
+    K.geom_cam = gc;
+    K.cull = gc + hd.n_objects;
+    K.geom_light = gt + hd.n_objects;
     K.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
     K.shadow_grid = (!plain && !no_grid) ? s->d_shadow_grid : nullptr;
     K.bounce_table = (!plain && !no_bounce) ? s->d_bounce_table : nullptr;
@@ -822,31 +1084,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   hipEvent_t &ev0 = ev.a, &ev1 = ev.b;
   if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
   static const bool no_order = RT_TEST_ENV("RT_NO_DISPATCH_ORDER") != nullptr;    // A/B switch (test build): the grid's own order
-  struct table_guard {                                   // a per-call launch table is released on every way out, after the stream has drained
+  struct marks_guard {                                   // a per-call mark list is released on every way out, after the stream has drained
     void *p = nullptr; hipStream_t st = nullptr;
-    ~table_guard() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
-  } temp_table, temp_marks;
-  rt_scene_dev::mark_state temp_state = {~0u, nullptr, nullptr, nullptr, 0u};
-  uint32_t order_index = ~0u;
-  if (!strict_main) {
-    bool temporary = false;
-    // workgroups no sphere can show in are marked in the table and store the background constant without tracing (rt_tables.cpp);
-    // the counting variant traces them like any other (its counters are what the caller wants)
-    static const bool no_sky_tiles = RT_TEST_ENV("RT_NO_SKY_TILES") != nullptr;   // A/B switch (test build)
-    const bool mark_sky = L.sky_fast != 0u && !count && !no_sky_tiles;
-    // per block and light, the spheres that can shadow a primary hit of the block at all, and the block's primary candidates
-    // (rt_tables.cpp); needs every lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
-    static const bool no_shadow_masks = RT_TEST_ENV("RT_NO_SHADOW_MASKS") != nullptr;   // A/B switch (test build)
-    const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
-    const bool name_candidates = !count && !no_shadow_masks;
-    uint32_t n_entries = 0;
-    L.order = (const uint32_t *)dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
-                                               shadow_masks, name_candidates, &n_entries, &temporary, &order_index);
-    if (!L.order) return RT_ERR_DEVICE;
-    if (temporary) { temp_table.p = (void *)L.order; temp_table.st = stream; }
-    L.order_n8 = (n_entries + 7u) / 8u;
-    L.grid_x = n_entries; L.grid_y = 1u;               // one workgroup per table entry (runs of sky blocks share one)
-  }
+    ~marks_guard() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
+  } temp_marks;
   int err = 0;
   uint32_t marks_read_slot = 0;
   const uint32_t *marks_read = nullptr;                 // stats: where this launch's mark count can be read afterwards
@@ -854,24 +1095,42 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   bool retraced_all = false;
   if (strict_main) err = rt_launch_trace_strict(&L, s->refract, count, ss2, lds_for(true), stream);
   else {
-    // ---- the product launch and, unless this frame is KNOWN to have nothing for it, the list-driven strict launch behind it ----
-    std::lock_guard<std::mutex> mk(s->mark_mu);
+    // ---- the product launch: its table (found, or built on the GPU for this camera), the trace, and - unless this frame is KNOWN
+    //      to have nothing for it - the list-driven strict launch behind it; one step for the threads of this process ----
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    // workgroups no sphere can show in are marked in the table and store the background constant without tracing (rt_block.h);
+    // the counting variant traces them like any other (its counters are what the caller wants)
+    static const bool no_sky_tiles = RT_TEST_ENV("RT_NO_SKY_TILES") != nullptr;   // A/B switch (test build)
+    const bool mark_sky = L.sky_fast != 0u && !count && !no_sky_tiles;
+    // per block and light, the spheres that can shadow a primary hit of the block at all, and the block's primary candidates;
+    // needs every lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
+    static const bool no_shadow_masks = RT_TEST_ENV("RT_NO_SHADOW_MASKS") != nullptr;   // A/B switch (test build)
+    const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
+    const bool name_candidates = !count && !no_shadow_masks;
+    const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
+                                  shadow_masks, name_candidates, stream);
+    if (oi < 0) return RT_ERR_DEVICE;
+    rt_scene_dev::order_entry &oe = s->orders[oi];
+    L.order = oe.T.entries;
+    // one workgroup per table entry (runs of sky blocks share one).  How many there are is known on the device; until the build's
+    // count has reached the host, one workgroup per BLOCK is launched: those behind the last entry read a zero slot and leave
+    const uint32_t n_known = known_value(oe.known, s->cam_gen);
+    L.order_n8 = (oe.n_blocks + 7u) / 8u;
+    L.grid_x = n_known ? n_known - 1u : oe.n_blocks;
+    L.grid_y = 1u;
     rt_scene_dev::mark_state *ms = nullptr;
-    if (order_index != ~0u) for (rt_scene_dev::mark_state &m : s->mark_states) if (m.order_index == order_index && m.stream == stream) ms = &m;
+    for (rt_scene_dev::mark_state &m : s->mark_states) if (m.order_index == (uint32_t)oi && m.stream == stream) ms = &m;
+    rt_scene_dev::mark_state temp_state = {~0u, stream, nullptr, nullptr, 0u};
     if (!ms) {
-      // first launch of this (table, stream) pair - or a per-call table: a list of its own, released with the table
-      constexpr size_t RT_MARK_STATES = 256;
+      // first launch of this (table, stream) pair: a list of its own (beyond RT_KNOWN_WORDS pairs: one per call, nothing cached)
       const size_t bytes = 16u + (size_t)RT_MARKS_CAP * 8u;
       uint32_t *d = nullptr;
       hipError_t e = hipMalloc((void **)&d, bytes);
       if (e == hipSuccess) e = hipMemsetAsync(d, 0, 16u, stream);
       if (e != hipSuccess) { if (d) (void)hipFree(d); return fail(RT_ERR_DEVICE, "mark list: %s", hipGetErrorString(e)); }
-      if (order_index == ~0u) { temp_marks.p = d; temp_marks.st = stream; temp_state = rt_scene_dev::mark_state{~0u, stream, d, nullptr, 0u}; ms = &temp_state; }
+      if (s->mark_states.size() >= RT_KNOWN_WORDS) { temp_marks.p = d; temp_marks.st = stream; temp_state.d_marks = d; ms = &temp_state; }
       else {
-        if (!s->h_known_pool && hipHostMalloc((void **)&s->h_known_pool, RT_MARK_STATES * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) memset(s->h_known_pool, 0, RT_MARK_STATES * sizeof(uint32_t));
-        else if (!s->h_known_pool) (void)hipGetLastError();
-        volatile uint32_t *known = (s->h_known_pool && s->mark_states.size() < RT_MARK_STATES) ? s->h_known_pool + s->mark_states.size() : nullptr;
-        s->mark_states.push_back(rt_scene_dev::mark_state{order_index, stream, d, known, 0u});
+        s->mark_states.push_back(rt_scene_dev::mark_state{(uint32_t)oi, stream, d, known_word(s, s->mark_states.size()), 0u});
         ms = &s->mark_states.back();
       }
     }
@@ -893,11 +1152,12 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
     if (!ss2 && (w & 1u)) { F.centre_col = (w - 1u) / 2u; centre_items += (uint64_t)tiles->n_tiles * tiles->tile_rows * n_frames; }
     const bool retrace_all = RT_TEST_ENV("RT_EXACT_ALL") != nullptr && !no_fixup;
-    const uint32_t known = (ms->h_known && !test_marks) ? *ms->h_known : 0u;        // 0: not known (yet); else the frame's mark count + 1
+    const uint32_t known = test_marks ? 0u : known_value(ms->h_known, s->cam_gen);        // 0: not known (yet); else the frame's mark count + 1
     const bool need = !no_fixup && (known != 1u || centre_items != 0 || retrace_all);
     if (err == 0 && need) {
       bind_kernel(F, true);                             // the scene in its own order, every sphere in the loops, the reference's own miss colour
-      F.marks_known = test_marks ? nullptr : (uint32_t *)ms->h_known;
+      F.marks_known = test_marks ? nullptr : (unsigned long long *)ms->h_known;
+      F.known_tag = (uint32_t)s->cam_gen;
       F.retrace_all = retrace_all ? 1u : 0u;
       retraced_all = retrace_all;
       uint64_t n_wg = (centre_items + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;
@@ -1149,6 +1409,19 @@ int ensure_rccl(int ndev) {
 int scene_for(int device, const void *blob, size_t bytes, rt_scene_dev **out) {
   device_state &D = G.dev[device];
   if (D.cached_scene && D.cached_blob.size() == bytes && memcmp(D.cached_blob.data(), blob, bytes) == 0) { *out = D.cached_scene; return RT_OK; }
+  // the same scene from another camera (an animation: lookAt per frame, main.js:92-100): the resident scene moves its camera
+  if (D.cached_scene && D.cached_blob.size() == bytes) {
+    const size_t c0 = offsetof(rt_scene_header, cam_origin), c1 = c0 + 12 * sizeof(double);
+    const uint8_t *a = D.cached_blob.data(), *b = (const uint8_t *)blob;
+    if (memcmp(a, b, c0) == 0 && memcmp(a + c1, b + c1, bytes - c1) == 0) {
+      const rt_scene_header *nh = (const rt_scene_header *)blob;
+      if (rt_scene_set_camera(D.cached_scene, nh->cam_origin, nh->cam_axis_x, nh->cam_axis_y, nh->cam_axis_z, nullptr) == RT_OK) {
+        memcpy(D.cached_blob.data() + c0, b + c0, c1 - c0);
+        *out = D.cached_scene;
+        return RT_OK;
+      }
+    }
+  }
   if (D.cached_scene) { rt_scene_free(D.cached_scene); D.cached_scene = nullptr; D.cached_blob.clear(); }
   rt_scene_dev *s = nullptr;
   const int rc = rt_scene_upload(device, blob, bytes, &s);

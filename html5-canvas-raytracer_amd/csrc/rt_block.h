@@ -1,0 +1,189 @@
+// rt_block.h — what the product kernel's launch table states about ONE block of samples, written once for the host
+// (rt_tables.cpp: build_launch_table, the CPU tests' oracle and the no-GPU probe) and for the device (rt_tables_gpu.hip: the
+// table as the library builds it, one work-item per block).  Plain binary64, IEEE sqrt and division, no contraction (both
+// translation units are compiled without it): the two builds give the same words.
+//
+// A block is the 32 x 8 pixels (x supersample) of one workgroup of the trace kernel.  The rays of its samples lie inside the
+// circular cone around the box's centre direction that contains its four corner directions (half-angle alpha); a sphere with
+// centre C (seen from the camera) and radius R is met by SOME ray of that cone only if the angle between the cone's axis and C
+// is at most alpha + asin(R / |C|).  From that, with margins far above the kernel's rounding:
+//   * touched    - can any sphere but the enclosing one show in the block?  If not, and the scene's background is a constant,
+//                  the block is SKY: its workgroup stores the constant and traces nothing;
+//   * candidates - the (at most two) loop-order spheres the block's primary rays can meet at all (count << 16 | second << 8 |
+//                  first), or 0 = no statement: the kernel then tests those and skips its cull;
+//   * shadow masks (at most two lights) - where can the block's primary hits lie?  On candidate sphere i at distances
+//                  t(c) = c - sqrt(c^2 - k), c = d.C, which over the cone is the interval between t at the largest and at the
+//                  smallest c, so inside the ball around the cone's axis point at the mid distance with radius^2 = (dt/2)^2 +
+//                  2 t2 m (1 - cos alpha); sphere j can stand between such a point and light k only if the angle between
+//                  (Q - L) and (C_j - L) is at most asin(rho / |Q - L|) + asin(R_j / |C_j - L|) and its nearest point is not
+//                  beyond the patch.  The union over the block's candidates, per light, is a 16-bit set of loop-order sphere
+//                  indices (0xffffffff = no statement: scan everything); with more than 16 loop spheres a light's set is stored
+//                  as empty (0) or not (0xffff);
+//   * cost       - 1 + the weights of the spheres whose screen rectangle (the primary-ray cull's) touches the block: what ranks
+//                  the blocks dearest first.
+#ifndef RT_BLOCK_H
+#define RT_BLOCK_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define RT_HD __host__ __device__
+#else
+#define RT_HD
+#endif
+
+#define RT_TABLE_SKY 1u          /* mark sky blocks */
+#define RT_TABLE_MASKS 2u        /* shadow masks */
+#define RT_TABLE_CANDS 4u        /* primary candidates */
+#define RT_TABLE_WIDE 8u         /* more than 16 loop spheres: a light's set is empty (0) or not (0xffff) */
+#define RT_TABLE_RANK 16u        /* list the blocks dearest first */
+#define RT_TABLE_GEOMETRY 32u    /* the camera is usable for the cone test (finite, non-zero axis sums, positive projection distance) */
+#define RT_SKY_RUN_MAX 32u       /* consecutive sky blocks of a row block that share ONE entry */
+#define RT_COST_MAX 1023u        /* costs are clamped here (the ranking only has to order the blocks roughly) */
+
+// a sphere as the cone test sees it (one per sphere but the enclosing one, scene order)
+struct rt_ball {
+  double c[3];                   // unit vector from the camera to the centre (the raw difference when `everywhere`)
+  double o[3];                   // the centre
+  double len, R, k;              // |centre - camera|, radius x (1 + 1e-7), len^2 - r^2 (with the TRUE radius: the tangent length bounds the hit distances)
+  double sin_b, cos_b;           // of asin(R / len)
+  uint32_t loop;                 // index in the product kernel's loop order (enclosing sphere last)
+  uint32_t everywhere;           // the camera is inside / on / too near: no statement about any block
+};
+
+// a sphere's screen rectangle on the workgroup grid and what a block that shows it is expected to cost
+struct rt_cost_rect { double ys0, ys1; uint32_t tx0, tx1, weight, pad; };
+
+struct rt_table_params {
+  double as0, as1, as2;          // camera axis sums (main.js:187-191, quirk q1)
+  double cam[3];
+  double proj_w, proj_h, proj_d; // of the sample grid
+  double epsilon;
+  double lights[2][3];
+  uint32_t tiles_x, ny, rb_per_tile;
+  uint32_t tile_rows, tile_first, tile_stride, n_tiles;
+  uint32_t ss, rows_per_wg, wg_w, wg_h;     // output rows / samples a workgroup covers
+  uint32_t w, h;
+  uint32_t n_balls, n_lights, n_rects, flags;
+  uint32_t cost_bins;            // a block's cost lies in 1 .. cost_bins (1 when the launch is not ranked)
+  uint32_t pad;
+};
+
+// first SAMPLE row of row block y of the launch
+RT_HD inline double rt_block_row0(const rt_table_params &P, uint32_t y) {
+  const uint32_t tile_i = y / P.rb_per_tile, rb = y - tile_i * P.rb_per_tile;
+  return ((double)(P.tile_first + (uint64_t)tile_i * P.tile_stride) * P.tile_rows + (double)rb * P.rows_per_wg) * P.ss;
+}
+
+RT_HD inline uint32_t rt_block_cost(const rt_table_params &P, const rt_cost_rect *rects, uint32_t x, uint32_t y) {
+  const double row0 = rt_block_row0(P, y);
+  uint32_t cost = 1u;
+  for (uint32_t j = 0; j < P.n_rects; j++) {
+    const rt_cost_rect &r = rects[j];
+    if (x < r.tx0 || x > r.tx1) continue;
+    if (row0 + P.wg_h <= r.ys0 || row0 > r.ys1) continue;
+    cost += r.weight;
+  }
+  return cost < RT_COST_MAX ? cost : RT_COST_MAX;
+}
+
+// touched / candidates / shadow masks of block (x, y); *touched = 1 also when nothing can be said
+RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *balls, uint32_t x, uint32_t y, uint32_t *touched, uint32_t *cands_out, uint32_t *smask_out) {
+  *touched = 1u; *cands_out = 0u; *smask_out = 0xffffffffu;
+  if (!(P.flags & RT_TABLE_GEOMETRY)) return;
+  const double row0 = rt_block_row0(P, y);
+  const double Y1 = (P.proj_h - 0.5) - row0, Y0 = Y1 - (double)(P.wg_h - 1u);
+  const double X0 = (double)((uint64_t)x * P.wg_w) + (0.5 - P.proj_w), X1 = X0 + (double)(P.wg_w - 1u);
+  const double cx[4] = {X0, X1, X0, X1}, cy[4] = {Y0, Y0, Y1, Y1};
+  double u[4][3], ax[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < 4; k++) {                      // the reference's ray: (s0 * X, s1 * Y, s2 * D), main.js:186-193 (q1)
+    const double dx = P.as0 * cx[k], dy = P.as1 * cy[k], dz = P.as2 * P.proj_d, l = sqrt(dx * dx + dy * dy + dz * dz);
+    u[k][0] = dx / l; u[k][1] = dy / l; u[k][2] = dz / l;
+    for (int c = 0; c < 3; c++) ax[c] += u[k][c];
+  }
+  const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  bool hit = !(al > 1e-3), doubt = hit;              // (a box wider than a half space: never at these fields of view)
+  double cos_a = 1.0;
+  if (!hit) {
+    for (int c = 0; c < 3; c++) ax[c] /= al;
+    for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
+    cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
+    hit = doubt = !(cos_a > 1e-3);
+  }
+  const double sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
+  // which spheres the cone can meet: a bit per ball (at most 256)
+  uint64_t cand[4] = {0ull, 0ull, 0ull, 0ull};
+  uint32_t n_cand = 0;
+  for (uint32_t j = 0; j < P.n_balls && !doubt; j++) {
+    const rt_ball &B = balls[j];
+    if (B.everywhere) { hit = doubt = true; break; }
+    const double cos_ab = cos_a * B.cos_b - sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
+    const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2];
+    if (!(cs < cos_ab - 1e-7)) { hit = true; cand[j >> 6] |= 1ull << (j & 63u); n_cand++; }   // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
+  }
+  *touched = hit ? 1u : 0u;
+  if (doubt || n_cand == 0u) return;
+  // word 3: count << 16 | loop index of the second << 8 | loop index of the first (in index order: the tie-break of the search)
+  if ((P.flags & RT_TABLE_CANDS) && n_cand <= 2u) {
+    uint32_t idx[2] = {0u, 0u}, got = 0;
+    for (uint32_t j = 0; j < P.n_balls && got < n_cand; j++) if (cand[j >> 6] >> (j & 63u) & 1ull) idx[got++] = balls[j].loop;
+    uint32_t i0 = idx[0], i1 = n_cand > 1u ? idx[1] : 0u;
+    if (n_cand > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
+    *cands_out = (n_cand << 16) | (i1 << 8) | i0;
+  }
+  if (!(P.flags & RT_TABLE_MASKS)) return;
+  uint32_t mk[2] = {0u, 0u};
+  for (uint32_t ci = 0; ci < P.n_balls; ci++) {
+    if (!(cand[ci >> 6] >> (ci & 63u) & 1ull)) continue;
+    const rt_ball &B = balls[ci];
+    // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
+    const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
+    const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
+    const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), sqrt(fmax(B.k, 0.0)));
+    // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
+    // to a sphere gets no statement)
+    if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(P.epsilon))) return;
+    const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
+    if (!(t2 >= t1) || !(t1 >= 0.0) || !(t2 <= 1.7976931348623157e308)) return;
+    const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
+    const double Q[3] = {P.cam[0] + m * ax[0], P.cam[1] + m * ax[1], P.cam[2] + m * ax[2]};
+    for (uint32_t k = 0; k < P.n_lights; k++) {
+      const double V[3] = {Q[0] - P.lights[k][0], Q[1] - P.lights[k][1], Q[2] - P.lights[k][2]};
+      const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+      for (uint32_t j = 0; j < P.n_balls; j++) {
+        if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
+        const rt_ball &O = balls[j];
+        const double W[3] = {O.o[0] - P.lights[k][0], O.o[1] - P.lights[k][1], O.o[2] - P.lights[k][2]};
+        const double wl = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);             // light to the occluder's centre
+        bool inc;
+        if (!(wl > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !(wl <= 1.7976931348623157e308) || !(dist <= 1.7976931348623157e308)) inc = true;     // light inside the occluder or the patch
+        else {
+          const double s1 = rho / dist, s2 = O.R / wl, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
+          const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * wl);
+          inc = !(cosang < cos12 - 1e-7) && (wl - O.R <= (dist + rho) * (1.0 + 1e-7));
+        }
+        if (inc) mk[k] |= (P.flags & RT_TABLE_WIDE) ? 0xffffu : (1u << O.loop);
+      }
+    }
+  }
+  *smask_out = mk[0] | (mk[1] << 16);
+}
+
+// the two words of an entry that describe WHERE its block is: word 0 = tile_x | rows_valid << 11 | first frame row << 15,
+// word 1 = first row in this call's output band (| (run - 1) << 24 | sky << 31, added by the caller)
+RT_HD inline void rt_block_place(const rt_table_params &P, uint32_t x, uint32_t y, uint32_t *w0, uint32_t *w1) {
+  const uint32_t tile_i = y / P.rb_per_tile, rb = y - tile_i * P.rb_per_tile;
+  const uint32_t trow0 = rb * P.rows_per_wg;                                             // first row of the block inside its tile
+  const uint64_t frow0 = (uint64_t)(P.tile_first + (uint64_t)tile_i * P.tile_stride) * P.tile_rows + trow0;
+  uint32_t rows_valid = 0;
+  if (trow0 < P.tile_rows && frow0 < P.h) {
+    rows_valid = P.rows_per_wg;
+    if (P.tile_rows - trow0 < rows_valid) rows_valid = P.tile_rows - trow0;
+    if (P.h - frow0 < rows_valid) rows_valid = (uint32_t)(P.h - frow0);
+  }
+  *w0 = (rows_valid << 11) | ((uint32_t)(frow0 < P.h ? frow0 : 0u) << 15) | x;              // frow0 < 65536 + 8: 17 bits
+  *w1 = tile_i * P.tile_rows + trow0;                                                      // < 2^24 (checked by the caller): bits 24..31 are free
+}
+
+#endif

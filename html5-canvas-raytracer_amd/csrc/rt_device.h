@@ -85,8 +85,10 @@ struct rt_launch {
   // Launch table of the product kernel (rt_api.hip: dispatch_order): workgroup b of the flat grid renders the tile described by
   // entry b = {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band}; the host lists the tiles
   // dearest first, so that a launch ends on cheap tiles.  The strict kernel runs on the plain 2-D grid and ignores it.
-  const uint32_t *order;
-  uint32_t order_n8;                 // ceil(workgroups / 8): entry of workgroup b sits at (b % 8) * order_n8 + b / 8 (one contiguous part per XCD)
+  const uint32_t *order;             // the entries; the four words in front of them are the table's header {entries, ceil(entries / 8), 0, 0}
+  uint32_t order_n8;                 // ceil(BLOCKS / 8): entry of workgroup b sits at (b % 8) * order_n8 + b / 8 (one contiguous part per XCD)
+                                     // (the slots behind the last entry are zero: a workgroup that reads one has no rows and leaves - the host launches one
+                                     // workgroup per BLOCK while it does not know the number of entries of a table built on the GPU a moment ago)
   uint32_t grid_x, grid_y;           // host side only: the product launch's flat grid (one workgroup per table entry; 0 = the plain 2-D grid)
   // Samples on exact coincidences.  A sample whose outcome in the reference hinges on the last bit of the reference's own
   // arithmetic is traced a second time with the reference's own operation sequence by the strict build's list-driven kernel
@@ -99,7 +101,8 @@ struct rt_launch {
   double flag_tol;                   // tolerance of the boundary test: RT_FLAG_T1 x the largest sampler frequency of the scene
   uint32_t mark_flags;               // RT_MARK_* (below)
   // rt_retrace only
-  uint32_t *marks_known;             // pinned host word that receives count + 1, or NULL
+  unsigned long long *marks_known;   // pinned host word that receives known_tag << 32 | count + 1, or NULL
+  uint32_t known_tag;                // (the camera generation the frame is rendered with)
   uint32_t centre_row, centre_col;   // frame row / column of the odd sample grid's centre within this call's tiles, or ~0u
   uint32_t retrace_all;              // test build (RT_EXACT_ALL): every sample of the call
 #ifdef RT_TESTING

@@ -1366,7 +1366,10 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t lane = tid & 63u;
   const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
 #if !RT_STRICT
-  if (P0.rows_valid == 0u) return;                     // workgroup-uniform: a block wholly past its tile's or the frame's last row
+  // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
+  // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last
+  // entry are zero (rt_tables_gpu.hip)
+  if (P0.rows_valid == 0u) return;
 #endif
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
@@ -1545,7 +1548,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
   const uint32_t count = L.marks[L.marks_slot];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     L.marks[L.marks_slot ^ 1u] = 0u;
-    if (L.marks_known) __hip_atomic_store(L.marks_known, count + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (L.marks_known) __hip_atomic_store(L.marks_known, ((unsigned long long)L.known_tag << 32) | (count + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint32_t band_rows = L.n_tiles * L.tile_rows;
   const bool everything = count > L.marks_cap || L.retrace_all != 0u;

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <vector>
 
+#include <string.h>
+
 #include "rt_tables.h"
 
 namespace rt_tables {
@@ -223,193 +225,135 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 }
 
 
-// The product kernel's launch table, and cost-ordered dispatch.  The product kernel runs on a FLAT grid and reads, per workgroup,
-// one 16-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band | (run - 1) << 24 | sky << 31,
-// shadow masks, primary candidates} (rt_kernel.hip: rt_pixel_of) - the tile / row-block arithmetic of the plain grid done once on
-// the host, plus what the host can tell a block in advance (sky blocks, shadow masks, candidates: below).  That also puts the ORDER in which
-// the hardware hands the tiles out in the host's hands.  In grid order a frame ends on whatever lies at the bottom right -
-// for the reference's scenes the floor and the sphere that both reflects and refracts, the dearest tiles of all - and the
-// last of them run alone on an otherwise idle chip.  For launches of many workgroups the host therefore ranks the tiles by a
-// cost estimate (the weights of the spheres whose screen rectangle - the primary-ray cull's - touches the tile) and lists
-// them dearest first, so the launch ends on sky.  Every tile is still rendered exactly once by exactly one workgroup: the
-// picture cannot change, only the tail does (measured: profiles/r02_ab_log.md).  Tables are cached per (frame size, tile set).
-// (`cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns RT_ENTRY_WORDS words per entry, 8 * ceil(n/8) entries;
-// empty on a launch that is too large for the table)
-std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
-                                         uint32_t w, uint32_t h, uint32_t ss,
-                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries) {
+// ------------------------------------------------------------------------------------ launch table (host side)
+// The product kernel runs on a FLAT grid and reads, per workgroup, one 16-byte entry {tile_x | rows_valid << 11 | first frame row <<
+// 15, first row in the output band | (run - 1) << 24 | sky << 31, shadow masks, primary candidates} (rt_kernel.hip: rt_pixel_of) -
+// the tile / row-block arithmetic of the plain grid done once, plus what can be told about a block in advance (rt_block.h: sky
+// blocks, shadow masks, candidates).  That also decides the ORDER in which the hardware hands the blocks out.  In grid order a frame
+// ends on whatever lies at the bottom right - for the reference's scenes the floor and the sphere that both reflects and refracts,
+// the dearest blocks of all - and the last of them run alone on an otherwise idle chip.  For launches of many workgroups the blocks
+// are therefore ranked by a cost estimate (the weights of the spheres whose screen rectangle - the primary-ray cull's - touches
+// the block) and listed dearest first, so the launch ends on sky; equal costs keep the grid's order (neighbours stay neighbours).
+// Every block is still rendered exactly once by exactly one workgroup: the picture cannot change, only the tail does (measured:
+// profiles/r02_ab_log.md).  Consecutive sky blocks of one row block are ONE entry (a run of up to RT_SKY_RUN_MAX blocks that does not
+// cross a multiple of RT_SKY_RUN_MAX: its workgroup stores the constant into each).
+//
+// The LIBRARY builds the table on the GPU (rt_tables_gpu.hip, one work-item per block, the same rt_block.h); what is here is the
+// part both share - the per-(scene, camera, frame size, tile set) parameters - and the host build: the oracle of the CPU tests
+// and of the -m gpu test that compares the two, and the no-GPU probe rt_scene_launch_table.
+
+// small launches have no tail worth ranking, and for very large ones (cfg5 on one GPU: 4.2 M workgroups, an 18 ms kernel) the
+// tail is noise; the COUNT variant and the A/B switch keep the grid's order as well
+bool table_is_ranked(bool ranked, uint64_t n_blocks) { return ranked && n_blocks >= 4096u && n_blocks <= (1u << 20); }
+
+int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
+                      uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d,
+                      bool ranked, bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3],
+                      rt_table_params *P, std::vector<rt_ball> *balls, std::vector<rt_cost_rect> *rects) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
-  if (n_entries) *n_entries = 0;
-  if (tiles_x > 2048u || n64 >= (1ull << 31) || n64 == 0) return {};   // (the caller reports it)
-  const uint32_t n = (uint32_t)n64;
-  const uint32_t rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                                // output rows a workgroup covers
-  const uint32_t wg_w = RT_TILE_W * ss, wg_h = rows_per_wg * ss;                        // ... and samples
-  // small launches have no tail worth ranking, and for very large ones (cfg5 on one GPU: 4.2 M workgroups, an 18 ms kernel) the
-  // tail is noise while the ranking itself would cost the host a few hundred ms; the COUNT variant and the A/B switch keep the
-  // grid's order as well
-  const bool rank = ranked && n >= 4096u && n <= (1u << 20);
-  std::vector<uint32_t> cost;
-  uint32_t cmax = 1;
-  if (rank) {
-    // per-tile cost: every sphere's rectangle, in sample coordinates, rasterised onto the workgroup grid
-    cost.assign(n, 1u);
-    const double W = (double)w * ss, H = (double)h * ss;
-    for (size_t j = 0; j < cull.size(); j++) {
-      const uint32_t wgt = weight[j];
-      if (!wgt) continue;
-      const rt_geom &r = cull[j];                    // {x_lo, x_hi, y_lo, y_hi} in units of 1/D; X = sx - W/2 + 0.5, Y = H/2 - sy - 0.5
-      const double sx0 = r.ox * proj_d + proj_w - 0.5, sx1 = r.oy * proj_d + proj_w - 0.5;
-      const double sy0 = proj_h - 0.5 - r.r2 * proj_d, sy1 = proj_h - 0.5 - r.oz * proj_d;        // y grows downwards
-      if (!(sx1 >= 0.0) || !(sx0 <= W) || !(sy1 >= 0.0) || !(sy0 <= H)) continue;            // off screen
-      const uint32_t tx0 = (uint32_t)(fmax(sx0, 0.0) / wg_w), tx1 = (uint32_t)fmin(fmin(sx1, W - 1.0) / wg_w, (double)(tiles_x - 1u));
-      const double ys0 = fmax(sy0, 0.0), ys1 = fmin(sy1, H - 1.0);
-      for (uint32_t y = 0; y < ny; y++) {
-        const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
-        const double row0 = ((double)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + (double)rb * rows_per_wg) * ss;   // first sample row
-        if (row0 + wg_h <= ys0 || row0 > ys1) continue;
-        for (uint32_t x = tx0; x <= tx1 && x < tiles_x; x++) cost[(size_t)y * tiles_x + x] += wgt;
-      }
-    }
-    for (uint32_t c : cost) cmax = c > cmax ? c : cmax;
-  }
-  // Sky tiles.  In a scene whose background is a constant (a flat enclosing sphere of plain colour, or no enclosing sphere at all:
-  // the miss colour) a workgroup none of whose primary rays can meet a sphere stores that constant and nothing else.  Which
-  // workgroups those are is decided here, geometrically and with margins far above the kernel's rounding: the rays of a
-  // workgroup's samples lie inside the circular cone around the box's centre direction that contains its four corner
-  // directions (half-angle alpha); a sphere with centre C (seen from the camera) and radius R is met by SOME ray of that cone
-  // only if the angle between the cone's axis and C is at most alpha + asin(R / |C|).  (The cull rectangles cannot decide this:
-  // they bound the pixels whose LINE meets a sphere, and the line of a sky pixel meets the ground sphere behind the camera.)
-  // Marked workgroups get bit 31 of their second word set and skip staging, ray generation, cull and trace (rt_kernel.hip);
-  // `sky_sphere` (scene order, or ~0u) is the enclosing sphere, which the product kernel's loops never test.
-  // Shadow masks (few spheres, at most two lights; `shadow_masks`).  For the same box the host also knows WHERE its primary hits
-  // can lie - on candidate sphere i at distances t(c) = c - sqrt(c^2 - k), c = d.C, which over the cone is the interval between
-  // t at the largest and at the smallest c, so inside the ball around the cone's axis point at the mid distance with radius^2 =
-  // (dt/2)^2 + 2 t2 m (1 - cos alpha) - and therefore which spheres can stand between such a point and light k at all: sphere j
-  // only if the angle between (Q - L) and (C_j - L) is at most asin(rho / |Q - L|) + asin(R_j / |C_j - L|) and its nearest point
-  // is not beyond the patch.  The union over the box's candidate spheres, per light, is a 16-bit set of loop-order sphere
-  // indices; the kernel's PRIMARY hits scan only those (rt_kernel.hip).  0xffffffff = no statement: scan everything.
-  std::vector<uint8_t> touched;
-  std::vector<uint32_t> smask, cands;      // cands: the (at most two) loop spheres a block's primary rays can meet at all, or 0 = no statement
-  const double as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0], as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1],
-               as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
+  if (tiles_x > 2048u || n64 >= (1ull << 31) || n64 == 0) return -1;   // (the caller reports it)
+  memset(P, 0, sizeof *P);
+  P->as0 = hd->cam_axis_x[0] + hd->cam_axis_y[0] + hd->cam_axis_z[0]; P->as1 = hd->cam_axis_x[1] + hd->cam_axis_y[1] + hd->cam_axis_z[1];
+  P->as2 = hd->cam_axis_x[2] + hd->cam_axis_y[2] + hd->cam_axis_z[2];
+  for (int c = 0; c < 3; c++) P->cam[c] = hd->cam_origin[c];
+  P->proj_w = proj_w; P->proj_h = proj_h; P->proj_d = proj_d; P->epsilon = hd->epsilon;
+  P->tiles_x = tiles_x; P->ny = ny; P->rb_per_tile = rb_per_tile;
+  P->tile_rows = tiles->tile_rows; P->tile_first = tiles->tile_first; P->tile_stride = tiles->tile_stride; P->n_tiles = tiles->n_tiles;
+  P->ss = ss; P->rows_per_wg = ss == 2u ? 2u : RT_TILE_H;                              // output rows a workgroup covers
+  P->wg_w = RT_TILE_W * ss; P->wg_h = P->rows_per_wg * ss;                              // ... and samples
+  P->w = w; P->h = h;
   const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
   const bool want_masks = shadow_masks && n_loop <= 256u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
   const bool want_cands = name_candidates && n_loop <= 256u;                 // (no light needed, and any enclosing sphere: it is outside the loops)
-  const bool wide = n_loop > 16u;           // more than 16 loop spheres: a light's set is stored as empty (0) or not (0xffff)
-  if ((mark_sky || want_masks || want_cands) && std::isfinite(as0) && std::isfinite(as1) && std::isfinite(as2) && as0 != 0.0 && as1 != 0.0 && as2 != 0.0 &&
-      std::isfinite(proj_d) && proj_d > 0.0) {
-    if (mark_sky) touched.assign(n, 0);
-    if (want_masks) smask.assign(n, 0xffffffffu);
-    if (want_cands) cands.assign(n, 0u);
-    struct ball { double c[3], o[3], len, R, k, sin_b, cos_b; uint32_t loop; bool everywhere; };
-    std::vector<ball> balls;
+  const bool geometry = std::isfinite(P->as0) && std::isfinite(P->as1) && std::isfinite(P->as2) && P->as0 != 0.0 && P->as1 != 0.0 && P->as2 != 0.0 &&
+                        std::isfinite(proj_d) && proj_d > 0.0;
+  P->flags = (mark_sky ? RT_TABLE_SKY : 0u) | (want_masks ? RT_TABLE_MASKS : 0u) | (want_cands ? RT_TABLE_CANDS : 0u) | (n_loop > 16u ? RT_TABLE_WIDE : 0u) |
+             (table_is_ranked(ranked, n64) ? RT_TABLE_RANK : 0u) | ((geometry && (mark_sky || want_masks || want_cands)) ? RT_TABLE_GEOMETRY : 0u);
+  P->cost_bins = 1u;
+  P->n_lights = want_masks ? hd->n_lights : 0u;
+  for (uint32_t k = 0; k < P->n_lights; k++) for (int c = 0; c < 3; c++) P->lights[k][c] = lights[k][c];
+  balls->clear();
+  if (P->flags & RT_TABLE_GEOMETRY)
     for (uint32_t j = 0; j < hd->n_objects; j++) {
       if (j == sky_sphere) continue;
-      ball B;
+      rt_ball B;
+      memset(&B, 0, sizeof B);
       for (int c = 0; c < 3; c++) { B.o[c] = ob[j].origin[c]; B.c[c] = ob[j].origin[c] - hd->cam_origin[c]; }
       B.len = sqrt(B.c[0] * B.c[0] + B.c[1] * B.c[1] + B.c[2] * B.c[2]);
       B.R = sqrt(ob[j].r2) * (1.0 + 1e-7);
       B.k = B.len * B.len - ob[j].r2;                    // with the TRUE radius: the tangent length sqrt(k) bounds the hit distances from above
       B.loop = (sky_sphere != ~0u && j > sky_sphere) ? j - 1u : j;       // index in the product kernel's loop order (enclosing sphere last)
-      B.everywhere = !(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7));      // camera inside / on / unknown
-      B.sin_b = B.cos_b = 0.0;
+      B.everywhere = (!(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7))) ? 1u : 0u;      // camera inside / on / unknown
       if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= B.len; B.sin_b = B.R / B.len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
-      balls.push_back(B);
+      balls->push_back(B);
     }
-    std::vector<uint32_t> cand;
-    for (uint32_t y = 0; y < ny; y++) {
-      const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
-      const double row0 = ((double)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + (double)rb * rows_per_wg) * ss;
-      const double Y1 = (proj_h - 0.5) - row0, Y0 = Y1 - (double)(wg_h - 1u);
-      for (uint32_t x = 0; x < tiles_x; x++) {
-        const double X0 = (double)((uint64_t)x * wg_w) + (0.5 - proj_w), X1 = X0 + (double)(wg_w - 1u);
-        const double cx[4] = {X0, X1, X0, X1}, cy[4] = {Y0, Y0, Y1, Y1};
-        double u[4][3], ax[3] = {0.0, 0.0, 0.0};
-        for (int k = 0; k < 4; k++) {                      // the reference's ray: (s0 * X, s1 * Y, s2 * D), main.js:186-193 (q1)
-          const double dx = as0 * cx[k], dy = as1 * cy[k], dz = as2 * proj_d, l = sqrt(dx * dx + dy * dy + dz * dz);
-          u[k][0] = dx / l; u[k][1] = dy / l; u[k][2] = dz / l;
-          for (int c = 0; c < 3; c++) ax[c] += u[k][c];
-        }
-        const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-        bool hit = !(al > 1e-3), doubt = hit;              // (a box wider than a half space: never at these fields of view)
-        double cos_a = 1.0;
-        if (!hit) {
-          for (int c = 0; c < 3; c++) ax[c] /= al;
-          for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
-          cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
-          hit = doubt = !(cos_a > 1e-3);
-        }
-        const double sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
-        cand.clear();
-        for (size_t j = 0; j < balls.size() && !doubt; j++) {
-          const ball &B = balls[j];
-          if (B.everywhere) { hit = doubt = true; break; }
-          const double cos_ab = cos_a * B.cos_b - sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
-          const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2];
-          if (!(cs < cos_ab - 1e-7)) { hit = true; cand.push_back((uint32_t)j); }   // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
-        }
-        const size_t at = (size_t)y * tiles_x + x;
-        if (mark_sky) touched[at] = hit ? 1 : 0;
-        if (doubt || cand.empty()) continue;
-        // word 3: count << 16 | loop index of the second << 8 | loop index of the first (in index order: the tie-break of the search)
-        if (want_cands && cand.size() <= 2u) {
-          uint32_t i0 = balls[cand[0]].loop, i1 = cand.size() > 1u ? balls[cand[1]].loop : 0u;
-          if (cand.size() > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
-          cands[at] = ((uint32_t)cand.size() << 16) | (i1 << 8) | i0;
-        }
-        if (!want_masks) continue;
-        uint32_t mk[2] = {0u, 0u};
-        bool ok = true;
-        for (uint32_t ci : cand) {
-          const ball &B = balls[ci];
-          // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
-          const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
-          const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
-          const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), sqrt(fmax(B.k, 0.0)));
-          // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
-          // to a sphere gets no statement)
-          if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(hd->epsilon))) { ok = false; break; }
-          const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
-          if (!(t2 >= t1) || !(t1 >= 0.0) || !std::isfinite(t2)) { ok = false; break; }
-          const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
-          const double Q[3] = {hd->cam_origin[0] + m * ax[0], hd->cam_origin[1] + m * ax[1], hd->cam_origin[2] + m * ax[2]};
-          for (uint32_t k = 0; k < hd->n_lights; k++) {
-            const double V[3] = {Q[0] - lights[k][0], Q[1] - lights[k][1], Q[2] - lights[k][2]};
-            const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-            for (size_t j = 0; j < balls.size(); j++) {
-              if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
-              const ball &O = balls[j];
-              const double W[3] = {O.o[0] - lights[k][0], O.o[1] - lights[k][1], O.o[2] - lights[k][2]};
-              const double wl = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);             // light to the occluder's centre
-              bool inc;
-              if (!(wl > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !std::isfinite(wl) || !std::isfinite(dist)) inc = true;     // light inside the occluder or the patch
-              else {
-                const double s1 = rho / dist, s2 = O.R / wl, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
-                const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * wl);
-                inc = !(cosang < cos12 - 1e-7) && (wl - O.R <= (dist + rho) * (1.0 + 1e-7));
-              }
-              if (inc) mk[k] |= wide ? 0xffffu : (1u << O.loop);
-            }
-          }
-        }
-        if (ok) smask[at] = mk[0] | (mk[1] << 16);
-      }
+  P->n_balls = (uint32_t)balls->size();
+  // per sphere: its cull rectangle, in sample coordinates, on the workgroup grid (the cost of a block: rt_block.h)
+  rects->clear();
+  if (P->flags & RT_TABLE_RANK) {
+    const double W = (double)w * ss, H = (double)h * ss;
+    for (size_t j = 0; j < cull.size(); j++) {
+      if (!weight[j]) continue;
+      const rt_geom &r = cull[j];                    // {x_lo, x_hi, y_lo, y_hi} in units of 1/D; X = sx - W/2 + 0.5, Y = H/2 - sy - 0.5
+      const double sx0 = r.ox * proj_d + proj_w - 0.5, sx1 = r.oy * proj_d + proj_w - 0.5;
+      const double sy0 = proj_h - 0.5 - r.r2 * proj_d, sy1 = proj_h - 0.5 - r.oz * proj_d;        // y grows downwards
+      if (!(sx1 >= 0.0) || !(sx0 <= W) || !(sy1 >= 0.0) || !(sy0 <= H)) continue;            // off screen
+      rt_cost_rect q;
+      q.tx0 = (uint32_t)(fmax(sx0, 0.0) / P->wg_w); q.tx1 = (uint32_t)fmin(fmin(sx1, W - 1.0) / P->wg_w, (double)(tiles_x - 1u));
+      q.ys0 = fmax(sy0, 0.0); q.ys1 = fmin(sy1, H - 1.0);
+      q.weight = weight[j]; q.pad = 0u;
+      rects->push_back(q);
     }
   }
+  P->n_rects = (uint32_t)rects->size();
+  // the costs a block of this launch can have: 1 .. cost_bins (what the ranking's per-row histograms are sized by); a launch whose
+  // histograms would be unreasonably large (tens of thousands of row blocks AND many dear spheres) keeps the grid's order
+  if (P->flags & RT_TABLE_RANK) {
+    uint64_t bound = 1u;
+    for (const rt_cost_rect &q : *rects) bound += q.weight;
+    P->cost_bins = (uint32_t)(bound < RT_COST_MAX ? bound : RT_COST_MAX);
+    if ((uint64_t)P->cost_bins * ny > (8u << 20)) { P->flags &= ~RT_TABLE_RANK; P->cost_bins = 1u; rects->clear(); P->n_rects = 0u; }
+  }
+  return 0;
+}
+
+// (`cull` = per-sphere screen rectangles, `weight` = per-sphere cost weights; returns RT_ENTRY_WORDS words per slot, 8 * ceil(blocks / 8) slots;
+// empty on a launch that is too large for the table)
+std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
+                                         uint32_t w, uint32_t h, uint32_t ss,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries) {
+  if (n_entries) *n_entries = 0;
+  rt_table_params P;
+  std::vector<rt_ball> balls;
+  std::vector<rt_cost_rect> rects;
+  if (make_table_params(hd, ob, cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, ranked, mark_sky, sky_sphere, shadow_masks, name_candidates, lights,
+                        &P, &balls, &rects)) return {};
+  const uint32_t ny = P.ny, n = tiles_x * ny;
+  const bool rank = (P.flags & RT_TABLE_RANK) != 0u;
+  std::vector<uint32_t> touched(n), cands(n), smask(n), cost(n, 1u);
+  for (uint32_t y = 0; y < ny; y++)
+    for (uint32_t x = 0; x < tiles_x; x++) {
+      const size_t at = (size_t)y * tiles_x + x;
+      rt_block_statement(P, balls.data(), x, y, &touched[at], &cands[at], &smask[at]);
+      if (rank) cost[at] = rt_block_cost(P, rects.data(), x, y);
+    }
   // The entries: one per workgroup.  A block that shows a sphere is an entry of its own; consecutive sky blocks of one row
   // block are ONE entry (a run of up to RT_SKY_RUN_MAX blocks: its workgroup stores the constant into each).
-  constexpr uint32_t RT_SKY_RUN_MAX = 32u;
   struct item { uint32_t y, x, run, cost; };
   std::vector<item> items;
   items.reserve(n);
+  uint32_t cmax = 1;
+  const bool sky = (P.flags & RT_TABLE_SKY) && (P.flags & RT_TABLE_GEOMETRY);
   for (uint32_t y = 0; y < ny; y++)
     for (uint32_t x = 0; x < tiles_x;) {
       const size_t at = (size_t)y * tiles_x + x;
-      if (touched.empty() || touched[at]) { items.push_back({y, x, 0u, rank ? cost[at] : 1u}); x++; continue; }
+      if (!sky || touched[at]) { items.push_back({y, x, 0u, cost[at]}); if (cost[at] > cmax) cmax = cost[at]; x++; continue; }
+      // (a run never crosses a multiple of RT_SKY_RUN_MAX blocks: whether a block starts a run is then a LOCAL question - its left
+      // neighbour, its own column - which is what lets the device build decide it per block)
       uint32_t run = 1;
-      while (x + run < tiles_x && run < RT_SKY_RUN_MAX && !touched[at + run]) run++;
+      while (x + run < tiles_x && (x + run) % RT_SKY_RUN_MAX != 0u && !touched[at + run]) run++;
       items.push_back({y, x, run, 1u});                  // (sky: base cost, last in the ranked order)
       x += run;
     }
@@ -421,28 +365,23 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
     for (const item &it : items) start[cmax - it.cost + 1u]++;
     for (uint32_t c = 0; c <= cmax; c++) start[c + 1u] += start[c];
   }
-  const uint32_t n8 = (n_items + 7u) / 8u;              // workgroup b's entry sits at (b % 8) * n8 + b / 8: one contiguous part per XCD
+  // workgroup b's entry sits at (b % 8) * n8 + b / 8, n8 = ceil(BLOCKS / 8): one contiguous part per XCD (workgroups are dealt
+  // round-robin over the 8 XCDs), at a stride the host knows before the number of entries is known (the device build's is only
+  // known on the device); the slots behind an XCD's last entry stay zero
+  const uint32_t n8 = (n + 7u) / 8u;
   std::vector<uint32_t> table((size_t)n8 * 8u * RT_ENTRY_WORDS, 0u);
   uint32_t next = 0;
+  const bool words23 = (P.flags & RT_TABLE_GEOMETRY) != 0u;
   for (const item &it : items) {
-    const uint32_t y = it.y;
-    const uint32_t tile_i = y / rb_per_tile, rb = y - tile_i * rb_per_tile;
-    const uint32_t trow0 = rb * rows_per_wg;                                             // first row of the block inside its tile
-    const uint64_t frow0 = (uint64_t)(tiles->tile_first + (uint64_t)tile_i * tiles->tile_stride) * tiles->tile_rows + trow0;
-    uint32_t rows_valid = 0;
-    if (trow0 < tiles->tile_rows && frow0 < h) {
-      rows_valid = rows_per_wg;
-      if (tiles->tile_rows - trow0 < rows_valid) rows_valid = tiles->tile_rows - trow0;
-      if (h - frow0 < rows_valid) rows_valid = (uint32_t)(h - frow0);
-    }
-    const uint32_t w0 = (rows_valid << 11) | ((uint32_t)(frow0 < h ? frow0 : 0u) << 15);        // frow0 < 65536 + 8: 17 bits
-    const uint32_t w1 = tile_i * tiles->tile_rows + trow0;                                    // < 2^24 (checked by the caller): bits 24..31 are free
+    uint32_t w0, w1;
+    rt_block_place(P, it.x, it.y, &w0, &w1);
     const uint32_t b = rank ? start[cmax - it.cost]++ : next++;                               // the workgroup that renders this entry
     const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
-    table[RT_ENTRY_WORDS * at] = w0 | it.x;
+    const size_t blk = (size_t)it.y * tiles_x + it.x;
+    table[RT_ENTRY_WORDS * at] = w0;
     table[RT_ENTRY_WORDS * at + 1u] = w1 | (it.run ? (0x80000000u | ((it.run - 1u) << 24)) : 0u);
-    table[RT_ENTRY_WORDS * at + 2u] = smask.empty() ? 0xffffffffu : smask[(size_t)it.y * tiles_x + it.x];
-    table[RT_ENTRY_WORDS * at + 3u] = cands.empty() ? 0u : cands[(size_t)it.y * tiles_x + it.x];
+    table[RT_ENTRY_WORDS * at + 2u] = (words23 && (P.flags & RT_TABLE_MASKS)) ? smask[blk] : 0xffffffffu;
+    table[RT_ENTRY_WORDS * at + 3u] = (words23 && (P.flags & RT_TABLE_CANDS)) ? cands[blk] : 0u;
   }
   return table;
 }

@@ -149,9 +149,10 @@ ABI = {
     "rt_scene_cull_rects": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
     "rt_scene_bounce_candidates": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rt_scene_launch_table": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_int, C.POINTER(C.c_uint32),
-                                        C.POINTER(C.c_uint32)]),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_scene_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "rt_scene_free": (None, [C.c_void_p]),
+    "rt_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_void_p, C.c_void_p,
                                          C.c_uint32, C.POINTER(RtStats)]),
     "rt_render_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(RtTiles), C.c_uint32, C.c_void_p, C.c_uint64,
@@ -194,7 +195,10 @@ def load_library(path=None):
         raise RtError("HIP library %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'`; "
                       "there is no CPU fallback for the render path" % p)
     lib = C.CDLL(p)
+    older = os.environ.get("RT_HIP_LIB_OLDER") == "1"    # A/B runs against a library built from an older revision (profiles/ab_run.sh)
     for name, (res, args) in ABI.items():
+        if older and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)        # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
     if path is None:
@@ -222,6 +226,12 @@ class Renderer:
         buf = C.create_string_buffer(self.blob, len(self.blob))
         _check(self.lib, self.lib.rt_scene_upload(device, buf, len(self.blob), C.byref(h)), "rt_scene_upload")
         self.handle = h
+
+    def set_camera(self, camera, stream=None):
+        """Move the camera of the resident scene (lookAt, main.js:92-100): `camera` = {"origin", "axisX", "axisY", "axisZ"}.  One small
+        asynchronous copy; the next render rebuilds what depends on it on the GPU."""
+        v = [(C.c_double * 3)(*camera[k]) for k in ("origin", "axisX", "axisY", "axisZ")]
+        _check(self.lib, self.lib.rt_scene_set_camera(self.handle, v[0], v[1], v[2], v[3], C.c_void_p(stream or 0)), "rt_scene_set_camera")
 
     def render_tiles(self, w, h, d_out, tiles=None, stream=None, flags=0, want_stats=False):
         t = tiles if isinstance(tiles, RtTiles) else RtTiles(*(tiles or (h, 0, 1, 1)))

@@ -170,23 +170,34 @@ int rt_scene_cull_rects(const void *scene_blob, size_t blob_bytes, double *out_4
  * set if sphere j is tested.  Conservative by construction: every sphere such a ray can meet is in the set. */
 int rt_scene_bounce_candidates(const void *scene_blob, size_t blob_bytes, uint32_t from, const double dir[3], uint64_t *out_words);
 
-/* Host-logic probe (no GPU): the launch table of the product kernel for `tiles` of the w x h frame (scene supersample 1 or 2).
+/* Host-logic probe (no GPU): the launch table of the product kernel for `tiles` of the w x h frame (scene supersample 1 or 2), as
+ * the HOST builds it; the library builds the same table on the GPU (same per-block source), per camera, frame size and tile set.
  * The kernel runs on a flat grid; workgroup b renders the 32-pixel-wide, 8-row (2 with supersample 2) block described by its
  * 16-byte entry {tile_x | rows_valid << 11 | first frame row << 15, first row in this call's output band | (run - 1) << 24 |
- * sky << 31, shadow masks, reserved}, stored at index (b % 8) * ceil(n / 8) + b / 8.  `ranked` is a bit set:
+ * sky << 31, shadow masks, primary candidates}, stored in slot (b % 8) * ceil(blocks / 8) + b / 8.  `ranked` is a bit set:
  *   1  the blocks are listed dearest first (a cost estimate from the spheres' screen rectangles), which is the order the
  *      hardware then hands them out in;
  *   2  blocks none of whose primary rays can meet a sphere are marked (sky = 1) and consecutive ones of a row block share one
- *      entry (run of blocks), as the launch of a scene with a constant background does: their workgroup stores the background;
+ *      entry (a run of blocks that does not cross a multiple of 32 blocks), as the launch of a scene with a constant background
+ *      does: their workgroup stores the background;
  *   4  word 2 = per light (16 bits each) the loop-order spheres that can shadow a primary hit of the block at all (scenes of at
- *      most 16 loop spheres and 2 lights; 0xffffffff = no statement).
- * out_entries: 32 * ceil(n / 8) words, or NULL to ask for *n_workgroups (= n, the number of entries) only. */
+ *      most 16 loop spheres and 2 lights; 0xffffffff = no statement), word 3 = the at most two spheres the block can show.
+ * out_entries: 32 * ceil(blocks / 8) words, or NULL to ask for *n_workgroups (the number of entries) and *n_blocks only. */
 int rt_scene_launch_table(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h, const rt_tiles *tiles, int ranked,
-                          uint32_t *out_entries, uint32_t *n_workgroups);
+                          uint32_t *out_entries, uint32_t *n_workgroups, uint32_t *n_blocks);
 
 /* Upload a scene to `device` (index into the GPUs in use) and keep it resident. */
 int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_scene_dev **out);
 void rt_scene_free(rt_scene_dev *scene);
+
+/* Move the camera of a resident scene (the reference's lookAt(), main.js:92-100: origin and the three axes; the reference
+ * recomputes everything on every redraw, main.js:180-201).  One small asynchronous copy on `hip_stream` (NULL = the library's
+ * stream for that device); what the library derives from the camera per frame size - the launch table - is rebuilt ON THE GPU by
+ * the next render, on its stream, with no host wait.  Renders and camera moves of one scene belong on ONE stream (others work:
+ * the device is drained first).  A camera that crosses the scene's enclosing sphere (a skybox) is RT_ERR_UNSUPPORTED: upload the
+ * scene again. */
+int rt_scene_set_camera(rt_scene_dev *scene, const double origin[3], const double axis_x[3], const double axis_y[3], const double axis_z[3],
+                        void *hip_stream);
 
 /* Render tiles of the w x h frame into DEVICE memory `d_out_rgba` (at least
  * n_tiles*tile_rows*w*4 bytes) on `hip_stream` (a hipStream_t; NULL = the library's own

@@ -6,7 +6,7 @@ for round in 1 2; do
 for v in "$@"; do
   LIB=$PWD/build/ab/librt_hip_$v.so
   [ "$v" = "product" ] && LIB=$PWD/html5-canvas-raytracer_amd/csrc/librt_hip.so
-  RT_HIP_LIB=$LIB python3 bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --no-pmc ${BENCH_ARGS:-} 2>gpurun_out/ab_err.log | python3 -c "
+  RT_HIP_LIB_OLDER=1 RT_HIP_LIB=$LIB python3 bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --no-pmc --no-cold ${BENCH_ARGS:-} 2>gpurun_out/ab_err.log | python3 -c "
 import json,sys
 l=sys.stdin.readline()
 try:

@@ -1142,3 +1142,106 @@ def test_rt_init_does_not_silently_change_the_device_count(lib):
     assert out["RC"] == ["0", "2", "-5", "0", "0", "-5", "2"], r.stdout
     assert "already initialised with 2 device(s)" in r.stdout
     assert out["RC2"] == ["0", "3"]
+
+
+def _look_at_camera(org, tgt, up=(0.0, 1.0, 0.0)):
+    import soak_gpu_parity as soak
+    return soak.look_at(list(org), list(tgt), list(up))
+
+
+def _gpu_table(tlib, renderer, w, h, tiles, ranked, ss=1):
+    t = rt_host.RtTiles(*tiles)
+    n, nb = C.c_uint32(), C.c_uint32()
+    tlib.rt_test_launch_table.restype = C.c_int
+    tlib.rt_test_launch_table.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(rt_host.RtTiles), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rows_per_wg = 2 if ss == 2 else 8
+    blocks = ((w + 31) // 32) * t.n_tiles * ((t.tile_rows + rows_per_wg - 1) // rows_per_wg)
+    out = (C.c_uint32 * (4 * (blocks + 8)))()
+    assert tlib.rt_test_launch_table(renderer.handle, w, h, C.byref(t), ranked, out, C.byref(n), C.byref(nb)) == 0, tlib.rt_last_error()
+    assert nb.value == blocks
+    return n.value, bytes(out)[:((blocks + 7) // 8) * 8 * 16]
+
+
+def _host_table(lib, blob, w, h, tiles, ranked):
+    buf = C.create_string_buffer(blob, len(blob))
+    t = rt_host.RtTiles(*tiles)
+    n, nb = C.c_uint32(), C.c_uint32()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), ranked, None, C.byref(n), C.byref(nb)) == 0, lib.rt_last_error()
+    out = (C.c_uint32 * (32 * ((nb.value + 7) // 8)))()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), ranked, out, C.byref(n), C.byref(nb)) == 0
+    return n.value, bytes(out)
+
+
+@pytest.mark.parametrize("scene,w,h,tiles", [
+    ("h8", 3840, 2160, (2160, 0, 1, 1)), ("h8", 3840, 2160, (16, 3, 8, 17)), ("h8", 1001, 333, (16, 1, 3, 7)), ("cfg2", 1920, 1080, (1080, 0, 1, 1)),
+    ("default14", 3840, 2160, (2160, 0, 1, 1)), ("default14", 203, 97, (97, 0, 1, 1)), ("lcg64", 4096, 1031, (24, 1, 2, 22)), ("lcg64_ss1", 3840, 2160, (2160, 0, 1, 1)),
+    ("cfg1", 256, 256, (256, 0, 1, 1)), ("cfg1", 1, 1, (1, 0, 1, 1)), ("h8", 65536, 8, (8, 0, 1, 1)), ("soak:31", 3840, 2160, (2160, 0, 1, 1)), ("soak:55", 3840, 2160, (2160, 0, 1, 1))])
+def test_the_launch_table_built_on_the_gpu_is_the_host_build_word_for_word(lib, scene, w, h, tiles):
+    """The launch table the library renders with is built ON THE GPU (rt_tables_gpu.hip: one work-item per block, rows segmented in
+    LDS, a stable counting sort by cost) from the same per-block source as the host build (rt_block.h, rt_tables.cpp - the oracle
+    of the CPU tests in tests/test_host.py): for every flag combination - ranked or not, sky blocks marked or not, shadow masks and
+    candidates or not - the two must agree in the number of entries and in every word of every entry; also after the camera has
+    moved (the table is rebuilt in place)."""
+    sc = _soak_scene(int(scene[5:]))[0] if scene.startswith("soak:") else rt_host.load_scene(scene)
+    if sc.get("supersample", 1) > 2:
+        sc["supersample"] = 1
+    tlib = rt_host.load_library(rt_host.TEST_LIB_PATH)
+    assert tlib.rt_init(1) == 0, tlib.rt_last_error()
+    blob = rt_host.flatten_scene(sc)
+    r = rt_host.Renderer(blob, 0, tlib)
+    try:
+        for ranked in range(8):
+            assert _gpu_table(tlib, r, w, h, tiles, ranked, sc.get("supersample", 1)) == _host_table(tlib, blob, w, h, tiles, ranked), (scene, ranked)
+        if not scene.startswith("soak:"):
+            cam0 = sc["camera"]["origin"]
+            for k in range(3):
+                sc["camera"] = _look_at_camera([cam0[0] + 0.7 * (k + 1), cam0[1] + 0.2 * k, cam0[2] - 0.5 * k], [0.3 * k, 1.0, 0.0])
+                r.set_camera(sc["camera"])
+                moved = rt_host.flatten_scene(sc)
+                for ranked in (7, 3, 5):
+                    assert _gpu_table(tlib, r, w, h, tiles, ranked, sc.get("supersample", 1)) == _host_table(tlib, moved, w, h, tiles, ranked), (scene, "moved", k, ranked)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("scene,w,h", [("h8", 640, 360), ("h8", 131, 77), ("default14", 320, 180), ("cfg2", 480, 270), ("lcg64_ss1", 192, 108), ("lcg64", 128, 72), ("cfg1", 128, 128)])
+def test_a_moved_camera_renders_what_a_fresh_upload_renders(lib, scene, w, h):
+    """rt_scene_set_camera (lookAt per frame, main.js:92-100; the reference recomputes everything per redraw, main.js:180-201):
+    a resident scene whose camera has moved - one small copy of the camera block, launch tables rebuilt on the GPU, mark counts
+    forgotten - must render the bytes a fresh upload of the moved scene renders, for both kernels, whole frames and interleaved
+    tiles, also when frames are queued without waiting in between; and rt_render, handed the same scene from another camera,
+    moves the resident scene's camera instead of uploading it again."""
+    sc = rt_host.load_scene(scene)
+    cam0 = list(sc["camera"]["origin"])
+    r = rt_host.Renderer(rt_host.flatten_scene(sc), 0, lib)
+    n = w * h * 4
+    d = lib.rt_alloc_device(0, 4 * n)
+    try:
+        cams = [_look_at_camera([cam0[0] + 1.3 * k - 2.0, cam0[1] + 0.35 * k, cam0[2] - 0.8 * k], [0.2 * k, 1.2, -0.3 * k]) for k in range(4)]
+        # four frames from four cameras, queued back to back on the library's stream, read afterwards
+        for k, cam in enumerate(cams):
+            r.set_camera(cam)
+            r.render_tiles(w, h, d + k * n, rt_host.RtTiles(h, 0, 1, 1))
+        host = C.create_string_buffer(4 * n)
+        assert lib.rt_copy_to_host(0, host, d, 4 * n) == 0
+        for k, cam in enumerate(cams):
+            sc["camera"] = cam
+            fresh = rt_host.flatten_scene(sc)
+            assert host.raw[k * n:(k + 1) * n] == gpu_frame(lib, fresh, w, h, FAST), (scene, k)
+            if k == 3:                                           # the resident scene still has camera 3: strict kernel, tiles
+                assert gpu_frame(lib, fresh, w, h, STRICT) == gpu_tiles(lib, fresh, w, h, (h, 0, 1, 1), STRICT)
+                st = r.render_tiles(w, h, d, rt_host.RtTiles(h, 0, 1, 1), flags=STRICT, want_stats=True)
+                assert lib.rt_copy_to_host(0, host, d, n) == 0
+                assert host.raw[:n] == gpu_frame(lib, fresh, w, h, STRICT)
+                band = gpu_tiles(lib, fresh, w, h, (8, 1, 3, (h // 8 + 2) // 3))
+                r.render_tiles(w, h, d, rt_host.RtTiles(8, 1, 3, (h // 8 + 2) // 3), want_stats=True)
+                assert lib.rt_copy_to_host(0, host, d, len(band)) == 0
+                assert host.raw[:len(band)] == band
+    finally:
+        lib.rt_free_device(0, d)
+        r.close()
+    # render(width, height, scene) with a moving scene.camera
+    for k in range(3):
+        sc["camera"] = _look_at_camera([cam0[0] - 0.9 * k, cam0[1] + 0.1, cam0[2] + 0.4 * k], [0.0, 1.0 + 0.2 * k, 0.0])
+        rgba, st = rt_host.render(w, h, sc)
+        assert bytes(rgba) == gpu_frame(lib, rt_host.flatten_scene(sc), w, h, FAST), (scene, "rt_render", k)

@@ -299,11 +299,11 @@ def _launch_table(lib, blob, w, h, tiles, ranked):
     import ctypes as C
     buf = C.create_string_buffer(blob, len(blob))
     t = rt_host.RtTiles(*tiles)
-    n = C.c_uint32()
-    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), None, C.byref(n)) == 0, lib.rt_last_error()
-    n8 = (n.value + 7) // 8
-    out = (C.c_uint32 * (32 * n8))()                         # 4 words per entry
-    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), out, C.byref(n)) == 0
+    n, nb = C.c_uint32(), C.c_uint32()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), None, C.byref(n), C.byref(nb)) == 0, lib.rt_last_error()
+    n8 = (nb.value + 7) // 8                                 # the table's stride comes from the number of BLOCKS
+    out = (C.c_uint32 * (32 * n8))()                         # 4 words per slot
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), int(ranked), out, C.byref(n), C.byref(nb)) == 0
     entries = []
     for b in range(n.value):
         at = (b % 8) * n8 + b // 8                           # one contiguous part of the table per XCD
