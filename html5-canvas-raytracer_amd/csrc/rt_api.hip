@@ -123,7 +123,8 @@ struct rt_scene_dev {
   uint64_t *d_bounce_table;      // bounce table for the same order, or NULL (few spheres, or depth < 2)
   uint8_t *d_lds_image;          // per ordering: [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)], the LDS image (in the camera block when it holds the rectangles)
   uint8_t *d_cam;                // the camera block: per ordering [anchored at the camera N | cull rectangles N], then the LDS images when they hold the rectangles
-  size_t cam_bytes;
+  size_t cam_bytes;              // (with the padding the many-sphere staging may read over)
+  size_t cam_bytes_used;         // what a camera move has to copy
   bool has_b;                    // two orderings (an enclosing sphere)
   bool cull_in_lds;
   size_t lds_image_bytes;        // of one ordering
@@ -135,7 +136,9 @@ struct rt_scene_dev {
   // pinned staging for the small copies that follow a camera move (the camera block; a launch table's parameters): a ring of slots,
   // each guarded by an event recorded behind the copy that read it
   struct stage_slot { uint8_t *h = nullptr; hipEvent_t done = nullptr; bool used = false; };
-  stage_slot stages[4];
+  stage_slot stages[16];                 // (16: the host may run eight frames ahead of the GPU in an animation; one pinned allocation behind them)
+  uint8_t *stage_pool = nullptr;
+  stage_slot *cam_pending = nullptr;     // a camera block staged by rt_scene_set_camera and not copied yet: the next launch's first step
   size_t stage_bytes = 0;
   uint32_t stage_next = 0;
   std::vector<uint8_t> host_blob;        // the scene as uploaded (patched: 1/r per sphere), for rebuilding the camera block
@@ -361,9 +364,19 @@ void camera_decisions(rt_scene_dev *s) {
   scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
 }
 
+// behind the launch that copied the staged camera block on `stream`
+hipError_t camera_copied(rt_scene_dev *s, rt_scene_dev::stage_slot *cam, hipStream_t stream) {
+  hipError_t e = hipEventRecord(cam->done, stream);
+  if (e == hipSuccess && !s->cam_ready) e = hipEventCreateWithFlags(&s->cam_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(s->cam_ready, stream);
+  s->cam_stream = stream;
+  s->cam_pending = nullptr;
+  return e;
+}
+
 // a staging slot of `bytes` (<= stage_bytes), free to be written: its previous copy has been read
 uint8_t *acquire_stage(rt_scene_dev *s, rt_scene_dev::stage_slot **slot) {
-  rt_scene_dev::stage_slot &g = s->stages[s->stage_next++ & 3u];
+  rt_scene_dev::stage_slot &g = s->stages[s->stage_next++ & 15u];
   if (g.used) (void)hipEventSynchronize(g.done);
   g.used = true;
   *slot = &g;
@@ -491,7 +504,8 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   const size_t off_sg = at; at = up(at + sg.size() * sizeof(uint64_t));
   const size_t off_bt = at; at = up(at + bt.size() * sizeof(uint64_t));
   const size_t off_cam = at;
-  s->cam_bytes = up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) + (s->cull_in_lds ? s->lds_image_bytes * n_ord + 4096u : 0);
+  s->cam_bytes_used = up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) + (s->cull_in_lds ? s->lds_image_bytes * n_ord : 0);
+  s->cam_bytes = s->cam_bytes_used + (s->cull_in_lds ? 4096u : 0);
   at = up(at + s->cam_bytes);
   s->arena_bytes = at;
   std::vector<uint8_t> host(at, 0);
@@ -538,10 +552,14 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   hipError_t e = hipMalloc((void **)&s->arena, s->arena_bytes);
   if (e == hipSuccess) e = hipMemcpy(s->arena, host.data(), s->arena_bytes, hipMemcpyHostToDevice);
   // pinned staging for what follows a camera move
-  s->stage_bytes = s->cam_bytes > 65536u ? s->cam_bytes : 65536u;
-  for (rt_scene_dev::stage_slot &g : s->stages) {
-    if (e == hipSuccess) e = hipHostMalloc((void **)&g.h, s->stage_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
+  {
+    const size_t table_dyn = 512u + (size_t)NO * (sizeof(rt_ball) + sizeof(rt_cost_rect));      // a launch table's parameters, cone-test spheres and cost rectangles
+    s->stage_bytes = up(s->cam_bytes > table_dyn ? s->cam_bytes : table_dyn);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->stage_pool, s->stage_bytes * 16u, hipHostMallocDefault);
+    for (size_t i = 0; i < 16u; i++) {
+      s->stages[i].h = s->stage_pool ? s->stage_pool + i * s->stage_bytes : nullptr;
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&s->stages[i].done, hipEventDisableTiming);
+    }
   }
   if (e != hipSuccess) {
     const std::string why = hipGetErrorString(e);
@@ -565,7 +583,8 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (G.inited && s->device < (int)G.dev.size()) (void)hipSetDevice(G.dev[s->device].hip_id);
   (void)hipDeviceSynchronize();                    // nothing of this scene is in flight any more
   if (s->arena) (void)hipFree(s->arena);
-  for (rt_scene_dev::stage_slot &g : s->stages) { if (g.h) (void)hipHostFree(g.h); if (g.done) (void)hipEventDestroy(g.done); }
+  for (rt_scene_dev::stage_slot &g : s->stages) if (g.done) (void)hipEventDestroy(g.done);
+  if (s->stage_pool) (void)hipHostFree(s->stage_pool);
   if (s->cam_ready) (void)hipEventDestroy(s->cam_ready);
   for (rt_scene_dev::order_entry &e : s->orders) free_order_entry(e);
   for (const rt_scene_dev::mark_state &m : s->mark_states) (void)hipFree(m.d_marks);
@@ -575,9 +594,10 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
 
 // The camera of a resident scene moves (lookAt, main.js:92-100; the reference recomputes everything per redraw, main.js:180-201).
 // What depends on it - the camera-anchored geometry, the cull rectangles, the LDS images that hold them - is ONE block of the
-// scene's arena, rewritten here with one small asynchronous copy on `hip_stream`; the launch tables of the scene are rebuilt on
-// the GPU by the next launch that needs them (dispatch_order).  Nothing waits for the GPU unless launches of this scene are in
-// flight on ANOTHER stream (then the device is drained first: they may still read the old block).
+// scene's arena; it is staged here (pinned host memory) and copied by the NEXT launch of the scene, on that launch's stream, by one
+// small kernel that also carries the parameters of the launch table that launch rebuilds on the GPU (dispatch_order).  Nothing
+// waits for the GPU unless launches of this scene are in flight on ANOTHER stream than that one (then the device is drained first:
+// they may still read the old block).
 extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], const double axis_x[3], const double axis_y[3], const double axis_z[3], void *hip_stream) {
   if (!s || !origin || !axis_x || !axis_y || !axis_z) return fail(RT_ERR_INVALID, "rt_scene_set_camera: NULL argument");
   int rc = ensure_device(s->device);
@@ -590,20 +610,18 @@ extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], cons
   // the two orderings of the scene's tables are built around the sphere that encloses everything INCLUDING the camera
   if (enclosing_sphere(&nh, s->host_objects.data(), s->lights) != s->enclosing)
     return fail(RT_ERR_UNSUPPORTED, "rt_scene_set_camera: the camera crossed the enclosing sphere (the scene's tables are laid out around it): upload the scene again");
-  if (s->any_launch && (s->several_streams || s->last_stream != stream)) HIP_TRY(hipDeviceSynchronize());
+  (void)stream;
   s->hd = nh;
   memcpy(s->host_blob.data(), &nh, sizeof nh);
   camera_decisions(s);
   s->cam_gen++;
+  // the block is staged now and copied by the next launch of the scene, on that launch's stream, together with what else that
+  // launch has to copy (a launch table's parameters): one small kernel
+  if (s->cam_pending) s->cam_pending->used = false;         // (a move nobody rendered: its slot is free again)
   rt_scene_dev::stage_slot *slot = nullptr;
   uint8_t *st = acquire_stage(s, &slot);
   fill_camera_block(s, st);
-  HIP_TRY((hipError_t)rt_launch_small_copy(s->d_cam, st, s->cam_bytes, stream));            // (a one-workgroup kernel that reads the pinned slot)
-  HIP_TRY(hipEventRecord(slot->done, stream));
-  if (!s->cam_ready) HIP_TRY(hipEventCreateWithFlags(&s->cam_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(s->cam_ready, stream));
-  s->cam_stream = stream;
-  s->any_launch = false; s->several_streams = false;
+  s->cam_pending = slot;
   return RT_OK;
 }
 
@@ -732,7 +750,7 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
     if (e.d_block) { (void)hipDeviceSynchronize(); (void)hipFree(e.d_block); e.d_block = nullptr; }
     auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
     const size_t cap_hist = hist_words > (size_t)P.ny * 128u ? hist_words : (size_t)P.ny * 128u;
-    const size_t dyn_bytes = up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_cost_rect));
+    const size_t dyn_bytes = up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_cost_rect)) + 256u;
     size_t at = 0;
     const size_t o_dyn = at; at += dyn_bytes;
     const size_t o_blk = at; at = up(at + (size_t)n * 12u);
@@ -742,12 +760,12 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
     const size_t o_bins = at; at = up(at + (size_t)(RT_COST_MAX + 1u) * 4u);
     const size_t o_head = at; at = up(at + 16u + ((size_t)(n + 7u) / 8u) * 8u * 16u);
     hipError_t er = hipMalloc((void **)&e.d_block, at);
+    if (er == hipSuccess) er = hipMemsetAsync(e.d_block + o_dyn + dyn_bytes - 256u, 0, 256u, stream);     // the scan's ticket
     if (er == hipSuccess && !e.built) er = hipEventCreateWithFlags(&e.built, hipEventDisableTiming);
     if (er != hipSuccess) { fail(RT_ERR_DEVICE, "launch table (%zu bytes): %s", at, hipGetErrorString(er)); return -1; }
     e.hist_words = cap_hist;
     e.T.params = (const rt_table_params *)(e.d_block + o_dyn);
-    e.T.balls = (const rt_ball *)(e.d_block + o_dyn + up(sizeof(rt_table_params)));
-    e.T.rects = (const rt_cost_rect *)(e.d_block + o_dyn + up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)));
+    e.T.ticket = (uint32_t *)(e.d_block + o_dyn + dyn_bytes - 256u);
     e.T.blk = (uint32_t *)(e.d_block + o_blk); e.T.item = (uint32_t *)(e.d_block + o_item); e.T.rank_in_row = (uint32_t *)(e.d_block + o_rank);
     e.T.row_hist = (uint32_t *)(e.d_block + o_hist); e.T.bin_start = (uint32_t *)(e.d_block + o_bins);
     e.T.header = (uint32_t *)(e.d_block + o_head); e.T.entries = e.T.header + 4;
@@ -759,19 +777,23 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
   e.cam_gen = s->cam_gen;
   e.T.known_tag = (uint32_t)s->cam_gen;
   e.built_on = stream; e.shared = false;
-  // parameters, cone-test spheres and cost rectangles: one staging slot, one asynchronous copy
-  auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+  // parameters, cone-test spheres and cost rectangles, packed: one staging slot, ONE small copy kernel - which also carries the
+  // scene's camera block if the camera has moved since the last launch (an SDMA copy in front of the build would cost two engine
+  // hand-overs, more than the copy)
   rt_scene_dev::stage_slot *slot = nullptr;
   uint8_t *st = acquire_stage(s, &slot);
-  const size_t o_balls = up(sizeof(rt_table_params)), o_rects = o_balls + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball));
+  const size_t o_balls = (sizeof(rt_table_params) + 15u) & ~(size_t)15u, o_rects = o_balls + balls.size() * sizeof(rt_ball);
   const size_t copy_bytes = o_rects + rects.size() * sizeof(rt_cost_rect);
+  e.T.balls = (const rt_ball *)((const uint8_t *)e.T.params + o_balls);
+  e.T.rects = (const rt_cost_rect *)((const uint8_t *)e.T.params + o_rects);
   memcpy(st, &P, sizeof P);
   if (!balls.empty()) memcpy(st + o_balls, balls.data(), balls.size() * sizeof(rt_ball));
   if (!rects.empty()) memcpy(st + o_rects, rects.data(), rects.size() * sizeof(rt_cost_rect));
-  // (copied by a one-workgroup kernel that reads the pinned slot: an SDMA copy in front of the build costs two engine hand-overs)
-  hipError_t er = (hipError_t)rt_launch_small_copy((void *)e.T.params, st, copy_bytes, stream);
+  rt_scene_dev::stage_slot *cam = s->cam_pending;
+  hipError_t er = (hipError_t)rt_launch_small_copy((void *)e.T.params, st, copy_bytes, cam ? s->d_cam : nullptr, cam ? cam->h : nullptr, cam ? s->cam_bytes_used : 0u, stream);
   if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
-  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, stream);
+  if (er == hipSuccess && cam) er = camera_copied(s, cam, stream);
+  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, stream);
   if (er == hipSuccess) er = hipEventRecord(e.built, stream);
   if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return -1; }
   return found;
@@ -910,7 +932,11 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
       const uint32_t band_rows = po.n_tiles * po.tile_rows;
       const size_t frame_words = (size_t)band_rows * k * w * k;
       void *scratch = nullptr;
+#ifdef RT_AB_POOLED_SCRATCH     /* experiment only (profiles/r03_ab_log.md): the stream-ordered allocator that corrupted one frame in round 2 */
+      hipError_t e = hipMallocAsync(&scratch, frame_words * 4u * n_frames, stream);
+#else
       hipError_t e = hipMalloc(&scratch, frame_words * 4u * n_frames);
+#endif
       if (e != hipSuccess) return fail(RT_ERR_NOMEM, "supersample scratch (%zu bytes): %s", frame_words * 4u * n_frames, hipGetErrorString(e));
 #ifdef RT_TESTING
       (void)hipMemsetAsync(scratch, 0xA5, frame_words * 4u * n_frames, stream);      // test build: a sample nobody writes shows up as 0xA5, not as stale data
@@ -932,8 +958,12 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
         e = hipGetLastError();
         if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "box filter launch: %s", hipGetErrorString(e));
       }
+#ifdef RT_AB_POOLED_SCRATCH
+      e = hipFreeAsync(scratch, stream);
+#else
       (void)hipStreamSynchronize(stream);            // (a 9x / 16x render: the allocation and this wait are noise beside it)
       e = hipFree(scratch);
+#endif
       if (rc) return rc;
       if (e != hipSuccess) return fail(RT_ERR_DEVICE, "supersample scratch release: %s", hipGetErrorString(e));
       if (stats) { agg.kernel_ms += st.kernel_ms; agg.rays += st.rays; agg.shadow_rays += st.shadow_rays; agg.sphere_tests += st.sphere_tests; }
@@ -971,7 +1001,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   {
     // which streams the scene's launches run on (rt_scene_set_camera, dispatch_order), and: behind the last write of the camera block
     std::lock_guard<std::mutex> lk(s->launch_mu);
-    if (s->cam_ready && s->cam_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->cam_ready, 0));
+    if (s->cam_pending) {
+      // the camera has moved: launches of this scene still in flight on ANOTHER stream may read the old block (rare: drain the device)
+      if (s->any_launch && (s->several_streams || s->last_stream != stream)) HIP_TRY(hipDeviceSynchronize());
+      s->any_launch = false; s->several_streams = false;
+    } else if (s->cam_ready && s->cam_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->cam_ready, 0));
     if (s->any_launch && s->last_stream != stream) s->several_streams = true;
     s->last_stream = stream; s->any_launch = true;
   }
@@ -1093,8 +1127,15 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   const uint32_t *marks_read = nullptr;                 // stats: where this launch's mark count can be read afterwards
   uint64_t centre_items = 0;
   bool retraced_all = false;
-  if (strict_main) err = rt_launch_trace_strict(&L, s->refract, count, ss2, lds_for(true), stream);
-  else {
+  if (strict_main) {
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    if (rt_scene_dev::stage_slot *cam = s->cam_pending) {          // the camera has moved: its block first
+      hipError_t e = (hipError_t)rt_launch_small_copy(s->d_cam, cam->h, s->cam_bytes_used, nullptr, nullptr, 0u, stream);
+      if (e == hipSuccess) e = camera_copied(s, cam, stream);
+      if (e != hipSuccess) return fail(RT_ERR_DEVICE, "camera block: %s", hipGetErrorString(e));
+    }
+    err = rt_launch_trace_strict(&L, s->refract, count, ss2, lds_for(true), stream);
+  } else {
     // ---- the product launch: its table (found, or built on the GPU for this camera), the trace, and - unless this frame is KNOWN
     //      to have nothing for it - the list-driven strict launch behind it; one step for the threads of this process ----
     std::lock_guard<std::mutex> lk(s->launch_mu);

@@ -48,6 +48,11 @@ struct rt_ball {
   double o[3];                   // the centre
   double len, R, k;              // |centre - camera|, radius x (1 + 1e-7), len^2 - r^2 (with the TRUE radius: the tangent length bounds the hit distances)
   double sin_b, cos_b;           // of asin(R / len)
+  double tangent;                // sqrt(max(k, 0)): the distance at which a ray from the camera grazes the sphere
+  // as an OCCLUDER seen from light k (at most two lights matter for the masks): centre - light, its length wl, wl - R, and sin / cos of
+  // asin(R / wl); `always`: the light is inside the sphere (or nothing finite can be said): it is in every set
+  double lw[2][3], wl[2], wl_minus_R[2], s2[2], c2[2];
+  uint32_t always[2];
   uint32_t loop;                 // index in the product kernel's loop order (enclosing sphere last)
   uint32_t everywhere;           // the camera is inside / on / too near: no statement about any block
 };
@@ -98,15 +103,16 @@ RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *ba
   const double cx[4] = {X0, X1, X0, X1}, cy[4] = {Y0, Y0, Y1, Y1};
   double u[4][3], ax[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < 4; k++) {                      // the reference's ray: (s0 * X, s1 * Y, s2 * D), main.js:186-193 (q1)
-    const double dx = P.as0 * cx[k], dy = P.as1 * cy[k], dz = P.as2 * P.proj_d, l = sqrt(dx * dx + dy * dy + dz * dz);
-    u[k][0] = dx / l; u[k][1] = dy / l; u[k][2] = dz / l;
+    const double dx = P.as0 * cx[k], dy = P.as1 * cy[k], dz = P.as2 * P.proj_d, il = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+    u[k][0] = dx * il; u[k][1] = dy * il; u[k][2] = dz * il;
     for (int c = 0; c < 3; c++) ax[c] += u[k][c];
   }
   const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
   bool hit = !(al > 1e-3), doubt = hit;              // (a box wider than a half space: never at these fields of view)
   double cos_a = 1.0;
   if (!hit) {
-    for (int c = 0; c < 3; c++) ax[c] /= al;
+    const double ial = 1.0 / al;
+    for (int c = 0; c < 3; c++) ax[c] *= ial;
     for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
     cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
     hit = doubt = !(cos_a > 1e-3);
@@ -140,7 +146,7 @@ RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *ba
     // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
     const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
     const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
-    const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), sqrt(fmax(B.k, 0.0)));
+    const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), B.tangent);
     // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
     // to a sphere gets no statement)
     if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(P.epsilon))) return;
@@ -151,17 +157,18 @@ RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *ba
     for (uint32_t k = 0; k < P.n_lights; k++) {
       const double V[3] = {Q[0] - P.lights[k][0], Q[1] - P.lights[k][1], Q[2] - P.lights[k][2]};
       const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+      // the patch seen from the light: a cone of half-angle asin(rho / dist) around V (the light inside the patch: every sphere)
+      const bool patch_ok = (dist > rho * (1.0 + 1e-7)) && (dist <= 1.7976931348623157e308);
+      const double s1 = patch_ok ? rho / dist : 0.0, c1 = sqrt(1.0 - s1 * s1), reach = (dist + rho) * (1.0 + 1e-7);
       for (uint32_t j = 0; j < P.n_balls; j++) {
         if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
         const rt_ball &O = balls[j];
-        const double W[3] = {O.o[0] - P.lights[k][0], O.o[1] - P.lights[k][1], O.o[2] - P.lights[k][2]};
-        const double wl = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);             // light to the occluder's centre
-        bool inc;
-        if (!(wl > O.R * (1.0 + 1e-7)) || !(dist > rho * (1.0 + 1e-7)) || !(wl <= 1.7976931348623157e308) || !(dist <= 1.7976931348623157e308)) inc = true;     // light inside the occluder or the patch
-        else {
-          const double s1 = rho / dist, s2 = O.R / wl, c1 = sqrt(1.0 - s1 * s1), c2 = sqrt(1.0 - s2 * s2);
-          const double cos12 = c1 * c2 - s1 * s2, cosang = (V[0] * W[0] + V[1] * W[1] + V[2] * W[2]) / (dist * wl);
-          inc = !(cosang < cos12 - 1e-7) && (wl - O.R <= (dist + rho) * (1.0 + 1e-7));
+        bool inc = true;                             // light inside the occluder or the patch
+        if (patch_ok && !O.always[k]) {
+          // angle(V, W) <= asin(rho / dist) + asin(R / wl), as cosines scaled by |V| |W| (no division per sphere), and the occluder's
+          // nearest point not beyond the patch
+          const double cos12 = c1 * O.c2[k] - s1 * O.s2[k], vw = V[0] * O.lw[k][0] + V[1] * O.lw[k][1] + V[2] * O.lw[k][2];
+          inc = !(vw < (cos12 - 1e-7) * (dist * O.wl[k])) && (O.wl_minus_R[k] <= reach);
         }
         if (inc) mk[k] |= (P.flags & RT_TABLE_WIDE) ? 0xffffu : (1u << O.loop);
       }

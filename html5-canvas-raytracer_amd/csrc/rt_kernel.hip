@@ -16,8 +16,8 @@
 //   * one work-item per pixel (per SAMPLE when supersampling 2x2); a wave owns a compact 8x8 block so its
 //     64 rays take the same branches; 4 waves side by side make a 32x8 workgroup tile = whole
 //     128-byte framebuffer lines, each line written by exactly one workgroup (no cross-XCD sharing);
-//     product kernel: a FLAT grid whose workgroups look their tile up in a host-built launch table (one
-//     s_load_dwordx2: no tile arithmetic, no division) that lists the tiles dearest first, so a launch ends
+//     product kernel: a FLAT grid whose workgroups look their tile up in a launch table built on the GPU (one
+//     s_load_dwordx4: no tile arithmetic, no division) that lists the tiles dearest first, so a launch ends
 //     on cheap sky tiles (rt_api.hip: dispatch_order); strict kernel: the plain 2-D grid;
 //   * everything wave-uniform — camera, lights, loop bounds (kernarg) and the sphere tables walked by
 //     the uniform object loops (typed address_space(4)) — is read with SCALAR loads into SGPRs: the
@@ -437,11 +437,13 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   return P;
 }
 #else
-// Product kernel: a FLAT grid (workgroups, 1, frames of the batch) and a host-built table with one 8-byte entry per workgroup:
-//   word 0 = tile_x | rows_valid << 11 | first frame row << 15      word 1 = first row in this call's output band
-// (rt_api.hip: dispatch_order).  One scalar load replaces the tile / row-block arithmetic of the plain grid - no division, no
-// tile parameters in registers - and lets the host choose the ORDER in which the hardware hands the tiles out: dearest first,
-// so that a launch ends on cheap sky tiles instead of on the floor.  trow is the row inside the workgroup's block here.
+// Product kernel: a FLAT grid (workgroups, 1, frames of the batch) and a launch table with one 16-byte entry per workgroup:
+//   word 0 = tile_x | rows_valid << 11 | first frame row << 15      word 1 = first row in this call's output band | (run - 1) << 24 | sky << 31
+//   word 2 = shadow masks                                            word 3 = primary candidates
+// (built on the GPU per camera, frame size and tile set: rt_tables_gpu.hip, rt_block.h).  One scalar load replaces the tile /
+// row-block arithmetic of the plain grid - no division, no tile parameters in registers - and decides the ORDER in which the
+// hardware hands the tiles out: dearest first, so that a launch ends on cheap sky tiles instead of on the floor.  trow is the row
+// inside the workgroup's block here.
 template <bool SS2>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
   const uint32_t wave = tid >> 6, lane = tid & 63u;
@@ -1065,14 +1067,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #endif
                 for (; j + 2 <= NS; j += 2) {
 #if !RT_STRICT
-                  if (!GRID && ((mk >> j) & 3u) == 0u) continue;
+                  if (!GRID && j < 31u && ((mk >> j) & 3u) == 0u) continue;       // (sets name 16 spheres; the upper half of mk is all ones: beyond bit 30 every pair is scanned)
 #endif
                   const rt_geom_pair gp = rt_load_geom_pair32(gl, glo + j);
                   const rt_geom g0 = gp.a, g1 = gp.b;
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
 #if !RT_STRICT
-                if (j < NS && (GRID || ((mk >> j) & 1u))) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
+                if (j < NS && (GRID || j >= 32u || ((mk >> j) & 1u))) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
                 }
 #else
                 if (j < NS) { const rt_geom g0 = RT_LOAD(gl, glo + j); RT_SHADOW_U(j, g0) }
@@ -1344,6 +1346,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t image_vec = image_words >> 1;                                     // 16-byte units (GRID: the image is whole units)
   [[maybe_unused]] rt_u4 piece[RT_STAGE_PIECES];
   [[maybe_unused]] double stage0 = 0.0;
+#if !RT_STRICT && defined(RT_AB_ENTRY_FIRST)
+  // (experiment: the table entry first - a workgroup without rows, or a sky workgroup, issues no staging load at all)
+  const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
+  if (P0.rows_valid == 0u) return;
+  if (!P0.sky) {
+#endif
   if constexpr (GRID) {
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
@@ -1351,6 +1359,9 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   } else {
     stage0 = (tid < image_words) ? image[tid] : 0.0;
   }
+#if !RT_STRICT && defined(RT_AB_ENTRY_FIRST)
+  }
+#endif
   const rt_mtl *mtl = (const rt_mtl *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
   const rt_geom *cull_lds = (const rt_geom *)(lds_raw + mtl_words + tex_words);
@@ -1364,7 +1375,9 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
+#if RT_STRICT || !defined(RT_AB_ENTRY_FIRST)
   const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
+#endif
 #if !RT_STRICT
   // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
   // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last

@@ -286,6 +286,15 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
       B.loop = (sky_sphere != ~0u && j > sky_sphere) ? j - 1u : j;       // index in the product kernel's loop order (enclosing sphere last)
       B.everywhere = (!(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7))) ? 1u : 0u;      // camera inside / on / unknown
       if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= B.len; B.sin_b = B.R / B.len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
+      B.tangent = sqrt(fmax(B.k, 0.0));
+      for (uint32_t k = 0; k < P->n_lights; k++) {      // the sphere as an occluder seen from light k
+        for (int c = 0; c < 3; c++) B.lw[k][c] = B.o[c] - lights[k][c];
+        B.wl[k] = sqrt(B.lw[k][0] * B.lw[k][0] + B.lw[k][1] * B.lw[k][1] + B.lw[k][2] * B.lw[k][2]);
+        B.always[k] = (!(B.wl[k] > B.R * (1.0 + 1e-7)) || !std::isfinite(B.wl[k])) ? 1u : 0u;
+        B.wl_minus_R[k] = B.wl[k] - B.R;
+        B.s2[k] = B.always[k] ? 0.0 : B.R / B.wl[k];
+        B.c2[k] = sqrt(1.0 - B.s2[k] * B.s2[k]);
+      }
       balls->push_back(B);
     }
   P->n_balls = (uint32_t)balls->size();

@@ -16,6 +16,7 @@ struct rt_table_dev {
   uint32_t *rank_in_row;           // per block: entries of the same cost to its left in the row
   uint32_t *row_hist;              // [row blocks][cost bins]: entries per cost, then their exclusive prefix down the rows
   uint32_t *bin_start;             // [cost bins]: first workgroup of a cost class
+  uint32_t *ticket;                // one word, zero between builds: which wave of rt_table_scan finishes last
   uint32_t *header;                // the table: 4 words {entries, ceil(entries / 8), 0, 0} ...
   uint32_t *entries;               // ... and 8 * ceil(blocks / 8) slots of 16 bytes behind them
   unsigned long long *known;       // pinned host word that receives known_tag << 32 | entries + 1, or NULL
@@ -23,8 +24,8 @@ struct rt_table_dev {
 };
 
 #ifdef __HIPCC__
-extern "C" int rt_launch_small_copy(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream);
-extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, hipStream_t stream);
+extern "C" int rt_launch_small_copy(void *dst0, const void *pinned_src0, size_t bytes0, void *dst1, const void *pinned_src1, size_t bytes1, hipStream_t stream);
+extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, hipStream_t stream);   // dyn_bytes: of (params | balls | rects), contiguous from T->params
 #endif
 
 #endif

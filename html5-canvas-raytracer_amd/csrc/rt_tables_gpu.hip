@@ -11,9 +11,9 @@
 //                   entry of its own, consecutive sky blocks share one (a run never crosses a multiple of 32 blocks, so "do I start a
 //                   run" is a question about the left neighbour) - how many entries of the same cost lie to the left of each (its
 //                   rank among equals in the row), and the row's histogram of entry costs;
-//   rt_table_scan   ONE workgroup: per cost, the exclusive prefix of the rows' histograms down the rows (a wave scans a column in
-//                   chunks of 64 rows), the totals, and their exclusive prefix from the dearest cost down: where each cost class
-//                   starts in the dispatch order.  Counting sort, stable: equal costs keep the grid's order, as on the host.  It
+//   rt_table_scan   one wave per cost: the exclusive prefix of the rows' histograms down the rows, the total; the wave that finishes
+//                   last (a ticket) scans the totals from the dearest cost down: where each cost class starts in the dispatch
+//                   order.  Counting sort, stable: equal costs keep the grid's order, as on the host.  It
 //                   also writes the table's header {entries, ceil(entries / 8)} and publishes the number of entries to the host;
 //   rt_table_emit   one work-item per block: an entry's workgroup index is class start + entries of its class in the rows above +
 //                   its rank in the row; its 16 bytes go to slot (b % 8) * ceil(blocks / 8) + b / 8 (one contiguous part per XCD).
@@ -32,9 +32,25 @@ namespace {
 
 constexpr uint32_t WG = 256;
 
-__global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T) {
-  extern __shared__ uint32_t lds[];
-  const rt_table_params &P = *T.params;
+// The parameters, the cone-test spheres and the cost rectangles are staged in LDS first - one coalesced load per work-item - and
+// read from there: every workgroup is the first on its CU to touch them (a copy kernel wrote them a moment ago), and as scalar
+// loads through the cold constant cache the ~30 dependent lines cost 20 of the kernel's 27 us (profiles/r03_ab_log.md).
+// `stage_bytes` = what of (params | balls | rects), contiguous from T.params on, goes to LDS.  STAGED = false: too many spheres for
+// it - they are read where they are.  (Two instantiations, so that in the staged one every read is known to be an LDS read: through
+// a pointer that may be either, each field is a flat load and its own wait - 20 us of dependent latencies per block.)
+template <bool STAGED>
+__global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32_t stage_bytes) {
+  extern __shared__ uint4 lds_raw[];
+  if (STAGED) {
+    const uint4 *src = (const uint4 *)T.params;
+    for (uint32_t i = threadIdx.x; i < stage_bytes / 16u; i += WG) lds_raw[i] = src[i];
+    __syncthreads();
+  }
+  const uint8_t *base = STAGED ? (const uint8_t *)lds_raw : (const uint8_t *)T.params;
+  const rt_table_params &P = *(const rt_table_params *)base;
+  const rt_ball *balls = (const rt_ball *)(base + ((const uint8_t *)T.balls - (const uint8_t *)T.params));
+  const rt_cost_rect *rects = (const rt_cost_rect *)(base + ((const uint8_t *)T.rects - (const uint8_t *)T.params));
+  uint32_t *lds = (uint32_t *)((uint8_t *)lds_raw + stage_bytes);
   const uint32_t y = blockIdx.x, tiles_x = P.tiles_x, bins = P.cost_bins;
   uint32_t *l_touched = lds;                 // [tiles_x] 1: shows a sphere (or no sky marking at all)
   uint32_t *l_key = lds + tiles_x;           // [tiles_x] entry starts: 1 + cost bin; 0: not an entry start
@@ -44,8 +60,16 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T) {
   for (uint32_t c = threadIdx.x; c < bins; c += WG) l_hist[c] = 0u;
   for (uint32_t x = threadIdx.x; x < tiles_x; x += WG) {
     uint32_t touched, cands, smask;
-    rt_block_statement(P, T.balls, x, y, &touched, &cands, &smask);
-    const uint32_t cost = rank ? rt_block_cost(P, T.rects, x, y) : 1u;
+#ifdef RT_TAB_NO_STMT   /* timing experiments (profiles/ab_build.sh) */
+    touched = 1u; cands = 0u; smask = 0xffffffffu;
+#else
+    rt_block_statement(P, balls, x, y, &touched, &cands, &smask);
+#endif
+#ifdef RT_TAB_NO_COST
+    const uint32_t cost = 1u + (x & 3u);
+#else
+    const uint32_t cost = rank ? rt_block_cost(P, rects, x, y) : 1u;
+#endif
     const size_t at = (size_t)y * tiles_x + x;
     T.blk[3u * at] = cost; T.blk[3u * at + 1u] = smask; T.blk[3u * at + 2u] = cands;
     l_touched[x] = (!sky || touched) ? 1u : 0u;
@@ -73,7 +97,9 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T) {
     const uint32_t key = l_key[x];
     if (!key) continue;
     uint32_t before = 0u;                                                                  // entries of the same cost to the left: the grid's order among equals
+#ifndef RT_TAB_NO_RANKLOOP
     for (uint32_t i = 0; i < x; i++) before += (l_key[i] == key) ? 1u : 0u;
+#endif
     T.rank_in_row[(size_t)y * tiles_x + x] = before;
   }
   for (uint32_t c = threadIdx.x; c < bins; c += WG) T.row_hist[(size_t)y * bins + c] = l_hist[c];
@@ -90,37 +116,45 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   return v;
 }
 
-__global__ void __launch_bounds__(1024) rt_table_scan(const rt_table_dev T) {
-  __shared__ uint32_t tot[RT_COST_MAX + 1u];
+// One wave per cost class: the exclusive prefix of the rows' counts down the rows (in place) and the class total; the wave that
+// finishes LAST (a ticket) turns the totals into class starts, writes the header and publishes the count.
+__global__ void __launch_bounds__(64) rt_table_scan(const rt_table_dev T) {
   const rt_table_params &P = *T.params;
-  const uint32_t bins = P.cost_bins, ny = P.ny, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  // per cost class: exclusive prefix of the rows' counts down the rows, in place; the class total
-  for (uint32_t c = wave; c < bins; c += n_waves) {
-    uint32_t carry = 0u;
-    for (uint32_t y0 = 0; y0 < ny; y0 += 64u) {
-      const uint32_t y = y0 + lane;
-      const uint32_t v = y < ny ? T.row_hist[(size_t)y * bins + c] : 0u;
-      const uint32_t inc = wave_inclusive_scan(v);
-      if (y < ny) T.row_hist[(size_t)y * bins + c] = carry + inc - v;
+  const uint32_t bins = P.cost_bins, ny = P.ny, lane = threadIdx.x, c = blockIdx.x;
+  uint32_t carry = 0u;
+  for (uint32_t y0 = 0; y0 < ny; y0 += 1024u) {
+    uint32_t v[16];
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) { const uint32_t y = y0 + i * 64u + lane; v[i] = y < ny ? T.row_hist[(size_t)y * bins + c] : 0u; }   // sixteen loads in flight
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) {
+      const uint32_t y = y0 + i * 64u + lane;
+      const uint32_t inc = wave_inclusive_scan(v[i]);
+      if (y < ny) T.row_hist[(size_t)y * bins + c] = carry + inc - v[i];
       carry += __shfl(inc, 63);
     }
-    if (lane == 0u) tot[c] = carry;
   }
-  __syncthreads();
+  uint32_t last = 0u;
+  if (lane == 0u) {
+    __hip_atomic_store(&T.bin_start[c], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the class total, for now
+    __threadfence();
+    last = (atomicAdd(T.ticket, 1u) == bins - 1u) ? 1u : 0u;
+  }
+  if (!__shfl(last, 0)) return;
+  __threadfence();
   // where each class starts (dearest first), and the number of entries
-  if (wave == 0u) {
-    uint32_t carry = 0u;
-    for (uint32_t c0 = 0; c0 < bins; c0 += 64u) {
-      const uint32_t c = c0 + lane;
-      const uint32_t v = c < bins ? tot[c] : 0u;
-      const uint32_t inc = wave_inclusive_scan(v);
-      if (c < bins) T.bin_start[c] = carry + inc - v;
-      carry += __shfl(inc, 63);
-    }
-    if (lane == 0u) {
-      T.header[0] = carry; T.header[1] = (carry + 7u) / 8u; T.header[2] = 0u; T.header[3] = 0u;
-      if (T.known) __hip_atomic_store(T.known, ((unsigned long long)T.known_tag << 32) | (carry + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+  uint32_t total = 0u;
+  for (uint32_t c0 = 0; c0 < bins; c0 += 64u) {
+    const uint32_t k = c0 + lane;
+    const uint32_t v = k < bins ? __hip_atomic_load(&T.bin_start[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (k < bins) T.bin_start[k] = total + inc - v;
+    total += __shfl(inc, 63);
+  }
+  if (lane == 0u) {
+    *T.ticket = 0u;                                       // for the next build
+    T.header[0] = total; T.header[1] = (total + 7u) / 8u; T.header[2] = 0u; T.header[3] = 0u;
+    if (T.known) __hip_atomic_store(T.known, ((unsigned long long)T.known_tag << 32) | (total + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -148,21 +182,24 @@ __global__ void __launch_bounds__(WG) rt_table_emit(const rt_table_dev T) {
 }  // namespace
 
 // A few KB from PINNED host memory (a staging slot) into device memory, by one workgroup on `stream`: what follows a camera move (the
-// scene's camera block, a launch table's parameters).  A copy engine would do it too, but its hand-overs to and from the compute
+// scene's camera block, a launch table's parameters: up to two pieces in one launch).  A copy engine would do it too, but its hand-overs to and from the compute
 // queue cost more than the copy.  `bytes` is rounded up to 16 (both buffers are 256-byte aligned and padded).
-__global__ void __launch_bounds__(256) rt_small_copy(uint4 *dst, const uint4 *src, uint32_t n16) {
-  for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = src[i];
+__global__ void __launch_bounds__(256) rt_small_copy(uint4 *dst0, const uint4 *src0, uint32_t n0, uint4 *dst1, const uint4 *src1, uint32_t n1) {
+  for (uint32_t i = threadIdx.x; i < n0 + n1; i += 256u) { if (i < n0) dst0[i] = src0[i]; else dst1[i - n0] = src1[i - n0]; }
 }
-extern "C" int rt_launch_small_copy(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(rt_small_copy, dim3(1), dim3(256), 0, stream, (uint4 *)dst, (const uint4 *)pinned_src, (uint32_t)((bytes + 15u) / 16u));
+extern "C" int rt_launch_small_copy(void *dst0, const void *pinned_src0, size_t bytes0, void *dst1, const void *pinned_src1, size_t bytes1, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_small_copy, dim3(1), dim3(256), 0, stream, (uint4 *)dst0, (const uint4 *)pinned_src0, (uint32_t)((bytes0 + 15u) / 16u),
+                     (uint4 *)dst1, (const uint4 *)pinned_src1, (uint32_t)((bytes1 + 15u) / 16u));
   return (int)hipGetLastError();
 }
 
 // Enqueue the three launches on `stream`.  Returns a hipError_t as int.
-extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, hipStream_t stream) {
+extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, hipStream_t stream) {
   const uint32_t n = tiles_x * ny;
-  hipLaunchKernelGGL(rt_table_rows, dim3(ny), dim3(WG), (2u * tiles_x + cost_bins) * sizeof(uint32_t), stream, *T);
-  hipLaunchKernelGGL(rt_table_scan, dim3(1), dim3(1024), 0, stream, *T);
+  const uint32_t stage_bytes = dyn_bytes <= 40u * 1024u ? ((dyn_bytes + 15u) & ~15u) : 0u;      // (params | balls | rects) of up to ~170 spheres fit LDS beside the row's arrays
+  if (stage_bytes) hipLaunchKernelGGL(rt_table_rows<true>, dim3(ny), dim3(WG), stage_bytes + (2u * tiles_x + cost_bins) * sizeof(uint32_t), stream, *T, stage_bytes);
+  else hipLaunchKernelGGL(rt_table_rows<false>, dim3(ny), dim3(WG), (2u * tiles_x + cost_bins) * sizeof(uint32_t), stream, *T, 0u);
+  hipLaunchKernelGGL(rt_table_scan, dim3(cost_bins), dim3(64), 0, stream, *T);
   hipLaunchKernelGGL(rt_table_emit, dim3((n + WG - 1u) / WG), dim3(WG), 0, stream, *T);
   return (int)hipGetLastError();
 }

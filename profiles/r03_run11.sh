@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 GPU call 11: per-kernel times of the moving-camera loop (rocprofv3 --kernel-trace --stats)
 mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_moving -- python3 $GRAFT_REPO_ROOT/profiles/moving_camera_loop.py h8 3840 2160 256 > $GRAFT_REPO_ROOT/gpurun_out/r03_moving_camera_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_moving -- python3 $GRAFT_REPO_ROOT/profiles/moving_camera_loop.py h8 3840 2160 256 > $GRAFT_REPO_ROOT/gpurun_out/r03_moving_camera_rocprof.log 2>&1
 tail -3 $GRAFT_REPO_ROOT/gpurun_out/r03_moving_camera_rocprof.log
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_moving -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
 import csv, sys
