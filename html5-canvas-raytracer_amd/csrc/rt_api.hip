@@ -1064,6 +1064,9 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
   };
   auto lds_for = [&](bool strict) {
+#ifdef RT_AB_LDS_SPHERES
+    if (!strict) return s->lds_bytes + lds_pad + (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u + s->hd.n_objects * 32u * (2u + s->hd.n_lights);     // EXPERIMENT: + the geometry tables
+#endif
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };

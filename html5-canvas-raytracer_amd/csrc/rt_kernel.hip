@@ -519,6 +519,14 @@ __device__ __forceinline__ const rt_launch __attribute__((address_space(4))) *rt
   asm volatile("" : "+s"(K));
   return K;
 }
+#ifdef RT_AB_LDS_SPHERES
+// EXPERIMENT: where the prologue staged the geometry tables in LDS (behind the LDS image and the fold state)
+template <bool REFRACT, bool GRID>
+__device__ __forceinline__ const double *rt_lds_tables(const rt_launch &L) {
+  extern __shared__ double lds_raw[];
+  return lds_raw + L.n_objects * ((uint32_t)(sizeof(rt_mtl) / 8) + (GRID ? 0u : 4u)) + 32u + (REFRACT ? 13u : 10u) * RT_WG_THREADS;
+}
+#endif
 // Append this work-item's sample to the launch's mark list (the cold end of the samplers' boundary test, a handful of samples per frame): entry = sample x |
 // sample y << 20 | frame of the batch << 40; the counter of THIS launch is marks[marks_slot] (rt_api.hip alternates two, so that
 // rt_retrace can clear the next launch's while it reads its own); beyond the list's capacity only the count grows and rt_retrace
@@ -607,7 +615,18 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
       // 32-bit byte offset (at most 256 spheres x 32 bytes, times at most 16 lights in the light-anchored table): base +
       // zext(offset) lets the scalar load take its offset from an SGPR (s_load_dwordx8 s[..], s[base], s_off) instead of
       // a 64-bit address computation per load (+0.8 % on the headline)
+#if !RT_STRICT && defined(RT_AB_LDS_SPHERES)
+      // EXPERIMENT (profiles/r03_ab_log.md; north_star: "sphere/light list staged in LDS"): the three geometry tables are staged into LDS
+      // behind the fold state by the kernel's prologue and every record is a broadcast LDS read into VECTOR registers
+      [[maybe_unused]] const rt_geom *const RT_LDS_geom = (const rt_geom *)rt_lds_tables<REFRACT, GRID>(L);
+      [[maybe_unused]] const rt_geom *const RT_LDS_gl = RT_LDS_geom + N;
+      [[maybe_unused]] const rt_geom *const RT_LDS_ga = RT_LDS_geom + (size_t)N * (1u + NL);
+#define RT_LOAD(TAB, I) (RT_LDS_##TAB[(uint32_t)(I)])
+#define RT_LOAD_PAIR(TAB, I) (rt_geom_pair{RT_LDS_##TAB[(uint32_t)(I)], RT_LDS_##TAB[(uint32_t)(I) + 1u]})
+#else
 #define RT_LOAD(TAB, I) rt_load_geom32((TAB), (uint32_t)(I))
+#define RT_LOAD_PAIR(TAB, I) rt_load_geom_pair32((TAB), (uint32_t)(I))
+#endif
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
       // the compiler's runtime unrolling); a pair's two records come with ONE s_load_dwordx16 (rt_load_geom_pair32).
   if (segs_left != 0) {
@@ -727,7 +746,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           ht = RT_INF; hcode = -1;
           uint32_t i = 0;
           for (; i + 2 <= NLOOP; i += 2) {
-            const rt_geom_pair gp = rt_load_geom_pair32(geom, i);
+            const rt_geom_pair gp = RT_LOAD_PAIR(geom, i);
             const rt_geom g0 = gp.a, g1 = gp.b;
             RT_GENERIC(i, g0) RT_GENERIC(i + 1, g1)
           }
@@ -926,7 +945,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             // hides behind the light vector's normalisation instead of standing in front of the scan (a wave whose lanes all
             // face away wasted one load); measured -0.3 % on the headline, and +0.4 % where the grid path made it a wasted load
             [[maybe_unused]] rt_geom_pair gp_first;
-            if constexpr (!GRID && !COUNT) gp_first = rt_load_geom_pair32((geom_kptr)L.geom_light, k * L.n_objects);
+            if constexpr (!GRID && !COUNT) {
+              [[maybe_unused]] const geom_kptr gl = (geom_kptr)L.geom_light;
+              gp_first = RT_LOAD_PAIR(gl, k * L.n_objects);
+            }
 #endif
             const v3 sraw = mk(lk[0] - h.x, lk[1] - h.y, lk[2] - h.z);
             const double lmag = dot(sraw, sraw);
@@ -1069,7 +1091,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #if !RT_STRICT
                   if (!GRID && j < 31u && ((mk >> j) & 3u) == 0u) continue;       // (sets name 16 spheres; the upper half of mk is all ones: beyond bit 30 every pair is scanned)
 #endif
-                  const rt_geom_pair gp = rt_load_geom_pair32(gl, glo + j);
+                  const rt_geom_pair gp = RT_LOAD_PAIR(gl, glo + j);
                   const rt_geom g0 = gp.a, g1 = gp.b;
                   RT_SHADOW_U(j, g0) RT_SHADOW_U(j + 1, g1)
                 }
@@ -1317,6 +1339,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
     }
   }
 #undef RT_LOAD
+#undef RT_LOAD_PAIR
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
 }
 
@@ -1434,6 +1457,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     if (tid < image_words) lds_raw[tid] = stage0;
     for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   }
+#if !RT_STRICT && defined(RT_AB_LDS_SPHERES)
+  {
+    double *tabs = (double *)rt_lds_tables<REFRACT, GRID>(L);
+    const uint32_t w1 = L.n_objects * 4u * (1u + L.n_lights), w2 = L.n_objects * 4u;          // [plain | lights] from L.geom, then the camera-anchored table
+    for (uint32_t k = tid; k < w1 + w2; k += RT_WG_THREADS) tabs[k] = k < w1 ? ((const double *)L.geom)[k] : ((const double *)L.geom_cam)[k - w1];
+  }
+#endif
   __syncthreads();
 
   // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)
