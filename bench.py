@@ -150,6 +150,28 @@ def pmc_passes(argv, kernel_substr="rt_trace"):
     return out, None
 
 
+def sky_block_fraction(lib, blob, w, h, tiles):
+    """Share of the 32 x 8 blocks of `tiles` that can only show the constant background (what RT_FLAG_NO_SKY leaves out), from the
+    host build of the launch table (a no-GPU probe of the library; reporting only)."""
+    import ctypes as C
+    import rt_host
+    buf = C.create_string_buffer(blob, len(blob))
+    t = rt_host.RtTiles(*tiles)
+    n, nb = C.c_uint32(), C.c_uint32()
+    if lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), 2, None, C.byref(n), C.byref(nb)) != 0 or nb.value == 0:
+        return 0.0
+    n8 = (nb.value + 7) // 8
+    out = (C.c_uint32 * (32 * n8))()
+    if lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), 2, out, C.byref(n), C.byref(nb)) != 0:
+        return 0.0
+    sky = 0
+    for b in range(n.value):
+        e1 = out[4 * ((b % 8) * n8 + b // 8) + 1]
+        if e1 >> 31:
+            sky += ((e1 >> 24) & 127) + 1
+    return sky / nb.value
+
+
 def look_at(org, tgt, up=(0.0, 1.0, 0.0)):
     """lookAt (main.js:92-100): the three camera axes from origin, target and up."""
     import numpy as np
@@ -302,497 +324,554 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    scene = rt_host.load_scene(scene_name)
-    ss = scene.get("supersample", 1)
-    lib = rt_host.load_library()
-    renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
-    flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
+    def run(single):
+        """One measurement: batch mode (single = False: N frames per step, frame f whole on rank f) or single-frame mode (True: ONE frame
+        per step, row-tiled over the ranks, whole on rank 0).  Returns (the JSON object on rank 0, parity_ok, max_lsb)."""
+        result = None
+        scene = rt_host.load_scene(scene_name)
+        ss = scene.get("supersample", 1)
+        lib = rt_host.load_library()
+        renderer = rt_host.Renderer(scene, dev_index, lib)          # scene resident in HBM from here on
+        flags = rt_host.RT_FLAG_STRICT_FP if args.strict_fp else 0
 
-    # Which ranks end up owning whole frames: every rank (batch mode: frame f of a step on rank f) or rank 0 alone
-    # (single-frame mode: the one frame of a step).
-    owners = [0] if (single and multi) else list(range(world))
-    i_own = rank in owners
-    frames_per_step = len(owners)
+        # Which ranks end up owning whole frames: every rank (batch mode: frame f of a step on rank f) or rank 0 alone
+        # (single-frame mode: the one frame of a step).
+        owners = [0] if (single and multi) else list(range(world))
+        i_own = rank in owners
+        frames_per_step = len(owners)
 
-    # Which plan reassembles the frames (module docstring).  The exchange plan is always set up unless peer stores are forced.
-    p2p_env = os.environ.get("RT_BENCH_P2P")
-    if p2p_env == "auto":                                                         # set both up and calibrate, at any N
-        p2p_env = None
-        p2p = multi
-    else:
-        p2p = multi and (p2p_env == "1" or (p2p_env is None and (world >= 6 or (single and world > 1))))
-    a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
-    plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
-    batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
-    # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
-    # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
-    # N>1: the render stream gets HIGH priority, so the exchange's copy kernels and the de-interleave (normal priority,
-    # memory-bound) fill in around the render instead of competing with it for wave slots (RT_BENCH_NO_PRIORITY=1: A/B)
-    hi_prio = multi and os.environ.get("RT_BENCH_NO_PRIORITY") != "1"
-    tstream = torch.cuda.Stream(device=dev, priority=-1) if hi_prio else torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
-    # N>1: ONE exchange serves `every` consecutive steps (RT_BENCH_EXCHANGE_EVERY, default 4; 1 for the 1 GiB frames of cfg5)
-    every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "1" if w * h >= (1 << 27) else "4"))) if multi else 1
-    # the frames this rank reassembles (N=1: the frame); ranks that own nothing keep a token allocation
-    frames = torch.empty((every, h, w, 4) if i_own else (1, 1, 1, 4), dtype=torch.uint8, device=dev)
-    frame = frames[0]
-    # Opt-in (RT_BENCH_TWO_STREAMS=1, N=1): consecutive frames alternate between two HIP streams and two frame
-    # buffers, so the tail of frame k overlaps the head of frame k+1 (+3 % measured).  Off by default so that
-    # every launch of the timed region runs alone and rocprof's per-kernel average equals `kernel_ms`.
-    two_streams = not multi and os.environ.get("RT_BENCH_TWO_STREAMS") == "1"
-    frame_b = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if two_streams else None
-    tstream_b = torch.cuda.Stream(device=dev) if two_streams else None
-    whole = rt_host.RtTiles(h, 0, 1, 1)
-    my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
-    frame_bytes = w * h * 4
-    import oracle_util as ou
+        # Which plan reassembles the frames (module docstring).  The exchange plan is always set up unless peer stores are forced.
+        p2p_env = os.environ.get("RT_BENCH_P2P")
+        if p2p_env == "auto":                                                         # set both up and calibrate, at any N
+            p2p_env = None
+            p2p = multi
+        else:
+            p2p = multi and (p2p_env == "1" or (p2p_env is None and (world >= 6 or (single and world > 1))))
+        a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
+        plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
+        batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
+        # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
+        # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
+        # N>1: the render stream gets HIGH priority, so the exchange's copy kernels and the de-interleave (normal priority,
+        # memory-bound) fill in around the render instead of competing with it for wave slots (RT_BENCH_NO_PRIORITY=1: A/B)
+        hi_prio = multi and os.environ.get("RT_BENCH_NO_PRIORITY") != "1"
+        tstream = torch.cuda.Stream(device=dev, priority=-1) if hi_prio else torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
+        assert stream != 0
+        # N>1: ONE exchange serves `every` consecutive steps (RT_BENCH_EXCHANGE_EVERY, default 4; 1 for the 1 GiB frames of cfg5)
+        every = max(1, int(os.environ.get("RT_BENCH_EXCHANGE_EVERY", "1" if w * h >= (1 << 27) else "4"))) if multi else 1
+        # the frames this rank reassembles (N=1: the frame); ranks that own nothing keep a token allocation
+        frames = torch.empty((every, h, w, 4) if i_own else (1, 1, 1, 4), dtype=torch.uint8, device=dev)
+        frame = frames[0]
+        # Opt-in (RT_BENCH_TWO_STREAMS=1, N=1): consecutive frames alternate between two HIP streams and two frame
+        # buffers, so the tail of frame k overlaps the head of frame k+1 (+3 % measured).  Off by default so that
+        # every launch of the timed region runs alone and rocprof's per-kernel average equals `kernel_ms`.
+        two_streams = not multi and os.environ.get("RT_BENCH_TWO_STREAMS") == "1"
+        frame_b = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if two_streams else None
+        tstream_b = torch.cuda.Stream(device=dev) if two_streams else None
+        whole = rt_host.RtTiles(h, 0, 1, 1)
+        my_tiles = rt_host.RtTiles(*plan.rt_tiles(rank))
+        frame_bytes = w * h * 4
+        import oracle_util as ou
 
-    def reference_rows():
-        """(rows, expected bytes) to check a reassembled frame against: the rows the reference itself rendered (tests/golden) when
-        this frame size has them, else a few rows from the oracle's C restatement (checker only, untimed)."""
-        for f in ou.manifest()["frames"]:
-            if f["scene"] == scene_name and (f["w"], f["h"]) == (w, h) and f["rows"]:
-                return f["rows"], ou.golden_frame(f), "tests/golden/%s (rendered by the reference itself)" % f["file"]
-        rows = sorted(set(int((k + 0.5) * h / 5) for k in range(5)))
-        blob = rt_host.flatten_scene(scene)
-        return rows, np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8), "oracle/rt_oracle.c rows %s" % rows
+        def reference_rows():
+            """(rows, expected bytes) to check a reassembled frame against: the rows the reference itself rendered (tests/golden) when
+            this frame size has them, else a few rows from the oracle's C restatement (checker only, untimed)."""
+            for f in ou.manifest()["frames"]:
+                if f["scene"] == scene_name and (f["w"], f["h"]) == (w, h) and f["rows"]:
+                    return f["rows"], ou.golden_frame(f), "tests/golden/%s (rendered by the reference itself)" % f["file"]
+            rows = sorted(set(int((k + 0.5) * h / 5) for k in range(5)))
+            blob = rt_host.flatten_scene(scene)
+            return rows, np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8), "oracle/rt_oracle.c rows %s" % rows
 
-    check_rows, check_bytes, check_source = reference_rows()
+        check_rows, check_bytes, check_source = reference_rows()
 
-    def worst_lsb(host_frame):
-        return int(ou.max_lsb(np.ascontiguousarray(host_frame[check_rows]).reshape(-1), check_bytes)[0])
+        def worst_lsb(host_frame):
+            return int(ou.max_lsb(np.ascontiguousarray(host_frame[check_rows]).reshape(-1), check_bytes)[0])
 
-    p2p_note = None
-    my_buf, peer_buf = None, {}
-    if p2p:
-        # Set-up and PRE-FLIGHT of the peer-store plan; anything that goes wrong on any rank (no IPC, no peer access, a frame
-        # that does not match the reference's rows) makes every rank fall back to the exchange plan, and the JSON says so.
-        import ctypes as C
-        problem, mine = None, None
-        try:
-            if i_own:
-                my_buf = lib.rt_alloc_device(dev_index, 2 * every * frame_bytes)      # [slot][step of the group] whole frames
-                if not my_buf:
-                    raise RuntimeError("rt_alloc_device: " + lib.rt_last_error().decode())
-                hnd = C.create_string_buffer(64)
-                if lib.rt_ipc_export(dev_index, my_buf, hnd) != 0:
-                    raise RuntimeError("rt_ipc_export: " + lib.rt_last_error().decode())
-                mine = hnd.raw
-            if os.environ.get("RT_BENCH_P2P_INJECT_FAILURE") == str(rank):     # test hook for the fallback
-                raise RuntimeError("injected failure on rank %d" % rank)
-        except Exception as e:      # noqa: BLE001
-            problem, mine = repr(e), None
-        handles = [None] * world
-        dist.all_gather_object(handles, (problem, mine))
-        if problem is None:
-            bad = [g for g in range(world) if handles[g][0] is not None or (g in owners and handles[g][1] is None)]
-            if bad:
-                problem = "rank %d: %s" % (bad[0], handles[bad[0]][0] or "could not export its buffer")
-        if problem is None:
+        p2p_note = None
+        my_buf, peer_buf = None, {}
+        # peer stores: the senders leave out the blocks in which only the constant background can show (RT_FLAG_NO_SKY), the owner of
+        # a frame stores them itself (RT_FLAG_SKY_ONLY): half of the headline's pixels never cross a link (RT_BENCH_SEND_SKY=1: A/B)
+        sky_out = 0 if (os.environ.get("RT_BENCH_SEND_SKY") == "1" or ss > 2) else rt_host.RT_FLAG_NO_SKY
+        if p2p:
+            # Set-up and PRE-FLIGHT of the peer-store plan; anything that goes wrong on any rank (no IPC, no peer access, a frame
+            # that does not match the reference's rows) makes every rank fall back to the exchange plan, and the JSON says so.
+            import ctypes as C
+            problem, mine = None, None
             try:
-                for g in owners:
-                    if g == rank:
-                        peer_buf[g] = my_buf
-                    else:
-                        q = C.c_void_p()
-                        hb = C.create_string_buffer(handles[g][1], 64)
-                        if lib.rt_ipc_open(dev_index, hb, C.byref(q)) != 0:
-                            raise RuntimeError("rt_ipc_open(rank %d): %s" % (g, lib.rt_last_error().decode()))
-                        peer_buf[g] = q.value
+                if i_own:
+                    my_buf = lib.rt_alloc_device(dev_index, 2 * every * frame_bytes)      # [slot][step of the group] whole frames
+                    if not my_buf:
+                        raise RuntimeError("rt_alloc_device: " + lib.rt_last_error().decode())
+                    hnd = C.create_string_buffer(64)
+                    if lib.rt_ipc_export(dev_index, my_buf, hnd) != 0:
+                        raise RuntimeError("rt_ipc_export: " + lib.rt_last_error().decode())
+                    mine = hnd.raw
+                if os.environ.get("RT_BENCH_P2P_INJECT_FAILURE") == str(rank):     # test hook for the fallback
+                    raise RuntimeError("injected failure on rank %d" % rank)
             except Exception as e:      # noqa: BLE001
-                problem = repr(e)
-        oks = [None] * world
-        dist.all_gather_object(oks, problem)
-        if all(x is None for x in oks):
-            # pre-flight: one step through the peer stores, then every owner checks the frame it owns
-            if i_own:
-                lib.rt_memset_device(dev_index, my_buf, 0, frame_bytes)
-            dist.barrier()
-            renderer.render_scatter(w, h, [peer_buf[g] for g in owners], my_tiles, flags=flags, want_stats=True)     # returns when the launch is done
-            dist.barrier()
-            worst = 0
-            if i_own:
-                host = np.empty((h, w, 4), dtype=np.uint8)
-                lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf, frame_bytes)
-                worst = worst_lsb(host)
-                if not (host[..., 3] == 255).all():
-                    worst = max(worst, 255)                                # a row nobody wrote
-                del host
-            worsts = [None] * world
-            dist.all_gather_object(worsts, worst)
-            if max(worsts) > 1:
-                oks = ["pre-flight frame differs from the reference's rows by %d LSB" % max(worsts)]
-        if not all(x is None for x in oks):
-            p2p_note = "peer-store plan not usable (%s): exchange plan used instead" % next(x for x in oks if x is not None)
+                problem, mine = repr(e), None
+            handles = [None] * world
+            dist.all_gather_object(handles, (problem, mine))
+            if problem is None:
+                bad = [g for g in range(world) if handles[g][0] is not None or (g in owners and handles[g][1] is None)]
+                if bad:
+                    problem = "rank %d: %s" % (bad[0], handles[bad[0]][0] or "could not export its buffer")
+            if problem is None:
+                try:
+                    for g in owners:
+                        if g == rank:
+                            peer_buf[g] = my_buf
+                        else:
+                            q = C.c_void_p()
+                            hb = C.create_string_buffer(handles[g][1], 64)
+                            if lib.rt_ipc_open(dev_index, hb, C.byref(q)) != 0:
+                                raise RuntimeError("rt_ipc_open(rank %d): %s" % (g, lib.rt_last_error().decode()))
+                            peer_buf[g] = q.value
+                except Exception as e:      # noqa: BLE001
+                    problem = repr(e)
+            oks = [None] * world
+            dist.all_gather_object(oks, problem)
+            if all(x is None for x in oks):
+                # pre-flight: one step through the peer stores, then every owner checks the frame it owns
+                if i_own:
+                    lib.rt_memset_device(dev_index, my_buf, 0, frame_bytes)
+                dist.barrier()
+                renderer.render_scatter(w, h, [peer_buf[g] for g in owners], my_tiles, flags=flags | sky_out, want_stats=True)     # returns when the launch is done
+                if i_own and sky_out:      # the sky blocks of the whole frame: the owner's own work, from its own launch table
+                    renderer.render_scatter(w, h, [my_buf], whole, flags=flags | rt_host.RT_FLAG_SKY_ONLY, want_stats=True)
+                dist.barrier()
+                worst = 0
+                if i_own:
+                    host = np.empty((h, w, 4), dtype=np.uint8)
+                    lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf, frame_bytes)
+                    worst = worst_lsb(host)
+                    if not (host[..., 3] == 255).all():
+                        worst = max(worst, 255)                                # a row nobody wrote
+                    del host
+                worsts = [None] * world
+                dist.all_gather_object(worsts, worst)
+                if max(worsts) > 1:
+                    oks = ["pre-flight frame differs from the reference's rows by %d LSB" % max(worsts)]
+            if not all(x is None for x in oks):
+                p2p_note = "peer-store plan not usable (%s): exchange plan used instead" % next(x for x in oks if x is not None)
+                if rank == 0:
+                    print("bench.py: " + p2p_note, file=sys.stderr, flush=True)
+                for g, q in peer_buf.items():
+                    if g != rank:
+                        lib.rt_ipc_close(dev_index, q)
+                peer_buf = {}
+                dist.barrier()
+                if my_buf:
+                    lib.rt_free_device(dev_index, my_buf)
+                    my_buf = None
+                p2p = False
+            else:
+                token = torch.zeros(1, dtype=torch.int32, device=ctl_dev)
+        # `mode["p2p"]`: the plan the step machinery below uses right now (the calibration switches it back and forth)
+        mode = {"p2p": p2p}
+        have_exchange = multi and not (p2p and p2p_env == "1")
+        if have_exchange:
+            if not single:
+                # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
+                send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+                recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+                host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
+            else:
+                # [step of the group][band] on every rank; rank 0 gathers [source rank][step][band]
+                send = [torch.empty((every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
+                recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) if i_own else None for _ in range(2)]
+                host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if (rehearse and i_own) else None
+        pending = []      # (work, slot, steps in it, plan) of exchanges in flight; at most 2
+        group = {"slot": 0, "fill": 0, "last_slot": 0}                 # the exchange buffer being filled, and how many steps are in it
+        # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
+        # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
+        side = torch.cuda.Stream(device=dev) if multi else None
+        slot_free = [torch.cuda.Event() for _ in range(2)] if multi else None
+
+        def render_step(slot, j=0):
+            if not multi:
+                renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
+            elif mode["p2p"]:   # frame of owner o in this step -> o's buffer, slot `slot`, position j; rows in frame order
+                off = (slot * every + j) * frame_bytes
+                renderer.render_scatter(w, h, [peer_buf[g] + off for g in owners], my_tiles, stream=stream, flags=flags | sky_out)
+                if i_own and sky_out:      # the sky blocks of the whole frame: the owner's own work (nothing of them crosses a link)
+                    renderer.render_scatter(w, h, [my_buf + off], whole, stream=stream, flags=flags | rt_host.RT_FLAG_SKY_ONLY)
+            elif not single:    # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
+                renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
+            else:               # this rank's tiles of the step's one frame -> send[slot][j]
+                renderer.render_batch(w, h, send[slot][j].data_ptr(), my_tiles, 1, 0, stream=stream, flags=batch_flags)
+
+        def finish(item):
+            work, slot, count, was_p2p = item
+            with torch.cuda.stream(side):
+                work.wait()                                          # the side stream waits for the exchange (p2p: the barrier)
+                if was_p2p or not i_own:
+                    count = 0                                        # the frames are already whole, in place (or live elsewhere)
+                elif rehearse:
+                    recv[slot].copy_(host_recv)
+                for j in range(count):                               # one whole frame per step of the group ends up on an owner
+                    shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
+                slot_free[slot].record(side)
+            tstream.wait_event(slot_free[slot])                      # ordering only: that work is two groups old by the time it matters
+
+        def launch_exchange():
+            slot = group["slot"]
+            if mode["p2p"]:
+                if rehearse:
+                    torch.cuda.synchronize()                          # gloo knows nothing of the GPU: finish the stores first
+                work = dist.all_reduce(token, async_op=True)          # after every rank's stores of this group (stream order)
+            elif not single:
+                work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True) if rehearse else shard.exchange_bands(send[slot], recv[slot], async_op=True)
+            elif rehearse:
+                work = shard.gather_bands(send[slot].cpu(), host_recv, dst=0, async_op=True)
+            else:
+                work = shard.gather_bands(send[slot], recv[slot], dst=0, async_op=True)
+            pending.append((work, slot, group["fill"], mode["p2p"]))   # overlaps with the renders of the next group
+            group["last_slot"] = slot
+            group["slot"], group["fill"] = slot ^ 1, 0
+
+        def step(k):
+            if not multi:
+                if two_streams and (k & 1):
+                    renderer.render_tiles(w, h, frame_b.data_ptr(), whole, stream=tstream_b.cuda_stream, flags=flags)
+                else:
+                    render_step(0)
+                return
+            if group["fill"] == 0 and len(pending) == 2:             # about to refill a slot: the exchange that last used it
+                finish(pending.pop(0))
+            render_step(group["slot"], group["fill"])
+            group["fill"] += 1
+            if group["fill"] == every:
+                launch_exchange()
+
+        def drain():
+            if multi and group["fill"] > 0:                      # a partial group still travels (whole buffer; only its steps count)
+                launch_exchange()
+            while pending:
+                finish(pending.pop(0))
+
+        def fence():
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        # initialisation, not a warm-up step: the first launch loads the code object, the first exchange builds the
+        # RCCL communicator (seconds) — both must be out of the way even when the caller asks for --warmup 0
+        step(0)
+        drain()
+        fence()
+
+        # What ONE of these GPUs does with the same frame on its own (rank 0, the others wait): the reference of efficiency_vs_n1
+        n1_mpix = None
+        if world > 1:
             if rank == 0:
-                print("bench.py: " + p2p_note, file=sys.stderr, flush=True)
+                tmp = frame if (i_own and frames.shape[1] == h) else torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+                k1 = max(10, min(400, int(0.05 / max(1e-6, w * h / 1e11))))
+                for _ in range(5):
+                    renderer.render_tiles(w, h, tmp.data_ptr(), whole, stream=stream, flags=flags)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k1):
+                    renderer.render_tiles(w, h, tmp.data_ptr(), whole, stream=stream, flags=flags)
+                torch.cuda.synchronize()
+                n1_mpix = w * h * k1 / (time.perf_counter() - t1) / 1e6
+            fence()
+
+        # Both plans are set up (nothing forced): time a few groups of steps with each and keep the faster one.  The
+        # slower rank decides (MAX over ranks), so every rank makes the same choice.
+        calibration = None
+        if multi and p2p and p2p_env is None:
+            def timed(n):
+                fence()
+                t0 = time.perf_counter()
+                for k in range(n):
+                    step(k)
+                drain()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+            calibration = {}
+            n_cal = max(every, min(8 * every, int(0.25 / max(1e-4, w * h / 6e10 / max(1, world if single else 1)))))   # ~0.25 s per plan at most
+            for name, flag in (("exchange", False), ("peer_stores", True)):
+                mode["p2p"] = flag
+                timed(every)                                   # this plan's own first-use costs
+                calibration[name] = round(timed(n_cal) / n_cal * 1e3, 4)      # ms per step
+            mode["p2p"] = calibration["peer_stores"] <= calibration["exchange"]
+            fence()
+
+        # ---- steady clocks first: trains of launches until two consecutive trains agree within 1 % and at least 50 ms have passed
+        #      (a GPU that has just been idle runs its first milliseconds below its sustained clock: a 5-step warm-up followed
+        #      by 20 timed steps would measure that transient, not the kernel) ----
+        settle = {"trains": 0, "ms": 0.0, "last_two_ms_per_step": None}
+        if os.environ.get("RT_BENCH_NO_SETTLE") != "1":
+            n_train = max(every, min(64, int(0.01 / max(1e-5, w * h / 6e10)) or 1))       # ~10 ms of launches per train
+            n_train = (n_train + every - 1) // every * every
+            prev, t_begin = None, time.perf_counter()
+            for _ in range(40):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(n_train):
+                    step(k)
+                drain()
+                torch.cuda.synchronize()
+                cur = (time.perf_counter() - t0) / n_train
+                settle["trains"] += 1
+                stop = prev is not None and abs(cur - prev) <= 0.01 * prev and (time.perf_counter() - t_begin) >= 0.05
+                settle["last_two_ms_per_step"] = [round(1e3 * x, 4) for x in (prev if prev is not None else cur, cur)]
+                prev = cur
+                if multi:                                            # every rank must leave the loop together
+                    tt = torch.tensor([0 if stop else 1], dtype=torch.int32, device=ctl_dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    stop = int(tt.item()) == 0
+                if stop:
+                    break
+            settle["ms"] = round(1e3 * (time.perf_counter() - t_begin), 1)
+            fence()
+
+        for k in range(args.warmup):
+            step(k)
+        drain()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fence()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+        channels = 4 if (not multi or mode["p2p"]) else a2a_channels          # bytes per pixel the chosen plan's launches store
+        # ---- dominant kernel: average launch duration, HIP events on the launch stream.  At N=1 the timed region IS a train of
+        #      these launches on this stream, so two events around a train of them give the average over every launch (what
+        #      rocprofv3's per-kernel average of the same command shows); at N>1 the region also waits for slots, so the kernel is
+        #      timed on a train of its own ----
+        fence()
+        n_train = max(20, min(args.steps, 2000)) if not multi else min(max(20, args.steps), 200)
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(min(10, n_train)):
+            render_step(0)
+        ev_a.record()
+        for _ in range(n_train):
+            render_step(0)
+        ev_b.record()
+        torch.cuda.synchronize()
+        kernel_ms = ev_a.elapsed_time(ev_b) / n_train
+        launch_pixels = w * h if not multi else frames_per_step * plan.pixels_of(rank)
+
+        # one more (untimed) group of steps; EVERY owner checks the frames it reassembled against the rows the reference itself
+        # rendered (tests/golden, fixtures) or, for a frame size without fixtures, a few rows of the C restatement
+        fence()
+        frames.zero_()
+        if p2p and i_own and lib.rt_memset_device(dev_index, my_buf, 0, 2 * every * frame_bytes) != 0:
+            raise SystemExit("bench.py: rt_memset_device: " + lib.rt_last_error().decode())
+        fence()                                                        # nobody stores into a buffer that is still being cleared
+        for k in range(every):                                         # one whole group, so every frame slot is rewritten
+            step(k)
+        drain()
+        fence()
+
+        def reassembled(j):
+            if not mode["p2p"]:
+                return frames[j].cpu().numpy()
+            host = np.empty((h, w, 4), dtype=np.uint8)
+            if lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf + (group["last_slot"] * every + j) * frame_bytes, frame_bytes) != 0:
+                raise SystemExit("bench.py: rt_copy_to_host: " + lib.rt_last_error().decode())
+            return host
+
+        max_lsb = 0
+        if i_own:
+            for j in range(every):
+                fr = reassembled(j)
+                max_lsb = max(max_lsb, worst_lsb(fr))
+                if not (fr[..., 3] == 255).all():
+                    max_lsb = 255                                          # a row nobody wrote
+                del fr
+        if world > 1:
+            t = torch.tensor([int(max_lsb)], dtype=torch.int64, device=ctl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            max_lsb = int(t.item())
+        parity_ok = max_lsb <= 1          # tolerance: 1 LSB per channel (SURVEY 8(c))
+        if rank == 0:
+            # work counters from the instrumented variant (untimed)
+            cnt_frame = frame if i_own and frames.shape[1] == h else torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            st = renderer.render_tiles(w, h, cnt_frame.data_ptr(), whole, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
+            rays_pp, shadow_pp, tests_pp = st.rays / st.pixels, st.shadow_rays / st.pixels, st.sphere_tests / st.pixels
+            total_pixels = w * h * frames_per_step * args.steps
+            value = total_pixels / elapsed / 1e6
+            flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
+            algo_bytes = float(channels) * launch_pixels        # what one launch stores: RGBA8, or RGB24 bands at N>1
+            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            # HBM traffic and executed FP64 instructions per launch: PMC passes over a short child run of this same command
+            traffic, traffic_src, fp64_measured = None, None, None
+            pmc, pmc_note = (None, "not collected (--no-pmc)") if (args.no_pmc or multi or os.environ.get("RT_BENCH_CHILD") == "1") else pmc_passes(
+                ["--config", args.config] + (["--scene", scene_name] if args.scene else [])
+                + (["--width", str(w)] if args.width else []) + (["--height", str(h)] if args.height else []) + (["--strict-fp"] if args.strict_fp else []))
+            if pmc:
+                traffic = pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0          # KiB -> bytes; FETCH_SIZE counts half (MI355X_MICROARCH.md, HBM)
+                traffic_src = "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) over a 12-step child run of this command; FETCH_SIZE doubled (gfx950)"
+                fl = (2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] + pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"]) * 64.0
+                fp64_measured = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "salu_insts_per_launch": pmc["SQ_INSTS_SALU"],
+                                 "fma_f64": pmc["SQ_INSTS_VALU_FMA_F64"], "add_f64": pmc["SQ_INSTS_VALU_ADD_F64"], "mul_f64": pmc["SQ_INSTS_VALU_MUL_F64"],
+                                 "trans_f64": pmc["SQ_INSTS_VALU_TRANS_F64"], "flop_per_launch_upper_bound": fl,
+                                 "achieved": round(fl / (kernel_ms * 1e-3) / 1e12, 3), "frac": round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
+                                 "note": "wave-instructions x 64 lanes (an upper bound: assumes a full exec mask), FMA = 2 flop; this run's counters, this run's kernel_ms"}
+                if "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"] > 0:
+                    # issue fractions: cycles in which a vector / scalar / any instruction was issued, per busy SQ cycle (SQ_ACTIVE_INST_* are
+                    # summed over an SQ's SIMDs, so VALU is also given per SIMD) and per resident wave-cycle
+                    fp64_measured["issue"] = {"valu_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"], 4),
+                                              "valu_per_busy_cycle_per_simd": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"] / 4.0, 4),
+                                              "scalar_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_SCA"] / pmc["SQ_BUSY_CYCLES"], 4),
+                                              "any_per_wave_cycle": round(pmc["SQ_ACTIVE_INST_ANY"] / pmc["SQ_WAVE_CYCLES"], 4) if pmc.get("SQ_WAVE_CYCLES") else None,
+                                              "counters": {k: pmc[k] for k in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY") if k in pmc}}
+                elif "issue_note" in pmc:
+                    fp64_measured["issue"] = {"note": pmc["issue_note"]}
+            else:
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")
+                key = "%s_%dx%d" % (scene_name, w, h)
+                if os.path.exists(tpath) and world == 1:
+                    tj = json.load(open(tpath))
+                    if key in tj:
+                        traffic = tj[key]["hbm_bytes_per_launch"]
+                        traffic_src = "REPLAYED from profiles/traffic.json (%s): %s" % (tj[key].get("source", "committed profile"), pmc_note)
+                        if "fp64" in tj[key]:
+                            fl = tj[key]["fp64"]["flop_per_launch_upper_bound"]
+                            fp64_measured = dict(tj[key]["fp64"], achieved=round(fl / (kernel_ms * 1e-3) / 1e12, 3),
+                                                 frac=round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
+                                                 note="counters REPLAYED from profiles/traffic.json, this run's kernel_ms")
+            if not multi:
+                how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
+            elif mode["p2p"]:
+                how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
+                       "frame buffer of the rank that owns each frame (peer-mapped over xGMI, RGBA8, rows in place): no data collective, no "
+                       "de-interleave; one all_reduce per %d steps is the barrier"
+                       % ("ONE frame, whole on rank 0" if single else "a batch of %d frames" % world, TILE_ROWS, world, every))
+            else:
+                how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank, ONE %s (RCCL over xGMI) "
+                       "reassembles %s (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
+                       "collective, which overlaps the renders of the next %d steps"
+                       % ("ONE frame" if single else "a batch of %d frames" % world, TILE_ROWS, world, "gather to rank 0" if single else "all-to-all",
+                          "the frame on rank 0" if single else "frame f on rank f", "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
+            # the store roofline as this box delivers it (SURVEY 8(d): quote a measured fill next to the nominal peak): a 2 GiB
+            # torch fill, best of 5, on the launch stream
+            fill_gbs = None
+            if not multi:
+                try:
+                    big = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+                    best = None
+                    for _ in range(6):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        big.fill_(7)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ms = e0.elapsed_time(e1)
+                        best = ms if best is None else min(best, ms)
+                    fill_gbs = round((2 << 30) / (best * 1e-3) / 1e9, 1)
+                    del big
+                except Exception:      # noqa: BLE001  (a small box: the nominal peak stands alone)
+                    fill_gbs = None
+            model_tf = flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12
+            out = {
+                "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (single and multi) else "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "%s: %s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; SCENE, CAMERA AND LAUNCH TABLE RESIDENT (a static frame rendered again and again: "
+                                       "cold_frame / new_camera_every_step are the other cases); %s" % (
+                    args.config if (scene_name, w, h) == CONFIGS[args.config][:3] else "custom", scene_name, len(scene["objects"]), len(scene["lights"]),
+                    scene["segs"], ss, w, h, how),
+                    "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step,
+                    "pixels_per_gpu_per_step": (w * h * frames_per_step) // world if multi else w * h,
+                    "steady_state_warmup": settle,
+                    **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {}),
+                    **({"FORCED_EXCHANGE": "the N>1 plan run by ONE rank (1-rank RCCL collective = self copy): the plan's own overhead, not the headline"} if force else {})},
+                "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
+                "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
+                "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok, "parity_checked_against": check_source,
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                             "traffic": traffic, "traffic_source": traffic_src, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4),
+                             "algorithmic_bytes_per_launch": algo_bytes,
+                             "measured_fill_GBs": fill_gbs, "frac_of_measured_fill": (round(achieved / fill_gbs, 6) if fill_gbs else None),
+                             "binding_bound": "fp64 vector issue under divergence (fp64_valu.measured), not HBM: the store roofline is the one the metric names",
+                             "note": "%d B per output pixel (one %s store); the path is FP64-VALU bound, see fp64_valu" % (channels, "RGBA8" if channels == 4 else "RGB24")},
+                "fp64_valu": {"peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "measured": fp64_measured,
+                              "reference_work_rate": {"flop_per_pixel": round(flops_pp, 1), "tflop_per_s_of_reference_work": round(model_tf, 3),
+                                                      "note": "NOT a utilisation: the REFERENCE's algorithmic operation count (SURVEY 8(d): 15/test + 120/ray + 60/shadow ray) per pixel x "
+                                                              "this kernel's pixel rate; the product kernel does not execute those operations (anchored tests are 4, not 10; sky workgroups, "
+                                                              "most floor blocks' shadow scans and the culled tests are never executed) - `measured` is what it executes"},
+                              "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
+            }
+            if n1_mpix:
+                out["n1_reference"] = {"mpixel_per_s": round(n1_mpix, 2), "note": "rank 0 alone, the same %dx%d frame, launches back to back, frame in HBM, measured in this run" % (w, h)}
+                out["efficiency_vs_n1"] = round(value / (world * n1_mpix), 4)
+            if p2p_note:
+                out["config"]["plan_note"] = p2p_note
+            if calibration:
+                out["config"]["plan_calibration_ms_per_step"] = calibration
+            if multi and mode["p2p"]:
+                sender = rank if any(g != rank for g in owners) else min(world - 1, 1)       # (single-frame mode: rank 0 owns, rank 1 sends)
+                remote_px = sum(1 for g in owners if g != sender) * plan.pixels_of(sender)
+                sky_frac = sky_block_fraction(lib, rt_host.flatten_scene(scene), w, h, plan.rt_tiles(sender)) if sky_out else 0.0
+                out["exchange"] = {"plan": "peer stores (rt_render_scatter_device through IPC-mapped frame buffers); the senders leave the constant-background blocks out "
+                                           "(RT_FLAG_NO_SKY), each owner stores them itself (RT_FLAG_SKY_ONLY)" if sky_out else
+                                           "peer stores (rt_render_scatter_device through IPC-mapped frame buffers), sky blocks included (RT_BENCH_SEND_SKY=1)",
+                                   "collective": "all_reduce of one int per group (barrier)",
+                                   "bytes_stored_remotely_per_rank_per_step": int(remote_px * 4 * (1.0 - sky_frac)),
+                                   "bytes_stored_remotely_per_rank_per_step_with_the_sky": remote_px * 4, "sky_fraction_of_this_ranks_blocks": round(sky_frac, 4),
+                                   "the_rank_these_are_for": sender, "steps_per_barrier": every}
+            elif multi:
+                out["exchange"] = {"plan": "exchange", "collective": "gather to rank 0" if single else "all_to_all_single",
+                                   "bytes_sent_per_rank_per_step": plan.band_bytes if single else (world - 1) * plan.band_bytes,
+                                   "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
+                                   "steps_per_collective": every}
+            if world == 1 and not args.no_cold and not args.strict_fp and os.environ.get("RT_BENCH_CHILD") != "1" and w * h <= 7680 * 4320:
+                try:
+                    out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(64, min(args.steps, 512))))
+                except Exception as e:   # noqa: BLE001  (the headline must still be reported)
+                    out["cold_frame"] = {"note": "failed: %r" % (e,)}
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(scene_name, w, h)
+                except Exception as e:   # the GPU number must still be reported
+                    out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
+            result = out
+
+        renderer.close()
+        if p2p:
+            fence()
             for g, q in peer_buf.items():
                 if g != rank:
                     lib.rt_ipc_close(dev_index, q)
-            peer_buf = {}
-            dist.barrier()
+            fence()
             if my_buf:
                 lib.rt_free_device(dev_index, my_buf)
-                my_buf = None
-            p2p = False
-        else:
-            token = torch.zeros(1, dtype=torch.int32, device=ctl_dev)
-    # `mode["p2p"]`: the plan the step machinery below uses right now (the calibration switches it back and forth)
-    mode = {"p2p": p2p}
-    have_exchange = multi and not (p2p and p2p_env == "1")
-    if have_exchange:
-        if not single:
-            # [destination rank][step of the group][band]: what all_to_all_single sends to rank g is send[g], contiguous
-            send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-            recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-            host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
-        else:
-            # [step of the group][band] on every rank; rank 0 gathers [source rank][step][band]
-            send = [torch.empty((every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
-            recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) if i_own else None for _ in range(2)]
-            host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if (rehearse and i_own) else None
-    pending = []      # (work, slot, steps in it, plan) of exchanges in flight; at most 2
-    group = {"slot": 0, "fill": 0, "last_slot": 0}                 # the exchange buffer being filled, and how many steps are in it
-    # the wait for an exchange and the de-interleaves that follow run on a SIDE stream, so the render stream
-    # never stalls behind communication; an event per slot tells the render stream when a slot may be reused
-    side = torch.cuda.Stream(device=dev) if multi else None
-    slot_free = [torch.cuda.Event() for _ in range(2)] if multi else None
+        return result, parity_ok, max_lsb
 
-    def render_step(slot, j=0):
-        if not multi:
-            renderer.render_tiles(w, h, frame.data_ptr(), whole, stream=stream, flags=flags)
-        elif mode["p2p"]:   # frame of owner o in this step -> o's buffer, slot `slot`, position j; rows in frame order
-            off = (slot * every + j) * frame_bytes
-            renderer.render_scatter(w, h, [peer_buf[g] + off for g in owners], my_tiles, stream=stream, flags=flags)
-        elif not single:    # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
-            renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
-        else:               # this rank's tiles of the step's one frame -> send[slot][j]
-            renderer.render_batch(w, h, send[slot][j].data_ptr(), my_tiles, 1, 0, stream=stream, flags=batch_flags)
 
-    def finish(item):
-        work, slot, count, was_p2p = item
-        with torch.cuda.stream(side):
-            work.wait()                                          # the side stream waits for the exchange (p2p: the barrier)
-            if was_p2p or not i_own:
-                count = 0                                        # the frames are already whole, in place (or live elsewhere)
-            elif rehearse:
-                recv[slot].copy_(host_recv)
-            for j in range(count):                               # one whole frame per step of the group ends up on an owner
-                shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
-            slot_free[slot].record(side)
-        tstream.wait_event(slot_free[slot])                      # ordering only: that work is two groups old by the time it matters
-
-    def launch_exchange():
-        slot = group["slot"]
-        if mode["p2p"]:
-            if rehearse:
-                torch.cuda.synchronize()                          # gloo knows nothing of the GPU: finish the stores first
-            work = dist.all_reduce(token, async_op=True)          # after every rank's stores of this group (stream order)
-        elif not single:
-            work = shard.exchange_bands(send[slot].cpu(), host_recv, async_op=True) if rehearse else shard.exchange_bands(send[slot], recv[slot], async_op=True)
-        elif rehearse:
-            work = shard.gather_bands(send[slot].cpu(), host_recv, dst=0, async_op=True)
-        else:
-            work = shard.gather_bands(send[slot], recv[slot], dst=0, async_op=True)
-        pending.append((work, slot, group["fill"], mode["p2p"]))   # overlaps with the renders of the next group
-        group["last_slot"] = slot
-        group["slot"], group["fill"] = slot ^ 1, 0
-
-    def step(k):
-        if not multi:
-            if two_streams and (k & 1):
-                renderer.render_tiles(w, h, frame_b.data_ptr(), whole, stream=tstream_b.cuda_stream, flags=flags)
-            else:
-                render_step(0)
-            return
-        if group["fill"] == 0 and len(pending) == 2:             # about to refill a slot: the exchange that last used it
-            finish(pending.pop(0))
-        render_step(group["slot"], group["fill"])
-        group["fill"] += 1
-        if group["fill"] == every:
-            launch_exchange()
-
-    def drain():
-        if multi and group["fill"] > 0:                      # a partial group still travels (whole buffer; only its steps count)
-            launch_exchange()
-        while pending:
-            finish(pending.pop(0))
-
-    def fence():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # initialisation, not a warm-up step: the first launch loads the code object, the first exchange builds the
-    # RCCL communicator (seconds) — both must be out of the way even when the caller asks for --warmup 0
-    step(0)
-    drain()
-    fence()
-
-    # Both plans are set up (nothing forced): time a few groups of steps with each and keep the faster one.  The
-    # slower rank decides (MAX over ranks), so every rank makes the same choice.
-    calibration = None
-    if multi and p2p and p2p_env is None:
-        def timed(n):
-            fence()
-            t0 = time.perf_counter()
-            for k in range(n):
-                step(k)
-            drain()
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item())
-        calibration = {}
-        n_cal = max(every, min(8 * every, int(0.25 / max(1e-4, w * h / 6e10 / max(1, world if single else 1)))))   # ~0.25 s per plan at most
-        for name, flag in (("exchange", False), ("peer_stores", True)):
-            mode["p2p"] = flag
-            timed(every)                                   # this plan's own first-use costs
-            calibration[name] = round(timed(n_cal) / n_cal * 1e3, 4)      # ms per step
-        mode["p2p"] = calibration["peer_stores"] <= calibration["exchange"]
-        fence()
-
-    # ---- steady clocks first: trains of launches until two consecutive trains agree within 1 % and at least 50 ms have passed
-    #      (a GPU that has just been idle runs its first milliseconds below its sustained clock: a 5-step warm-up followed
-    #      by 20 timed steps would measure that transient, not the kernel) ----
-    settle = {"trains": 0, "ms": 0.0, "last_two_ms_per_step": None}
-    if os.environ.get("RT_BENCH_NO_SETTLE") != "1":
-        n_train = max(every, min(64, int(0.01 / max(1e-5, w * h / 6e10)) or 1))       # ~10 ms of launches per train
-        n_train = (n_train + every - 1) // every * every
-        prev, t_begin = None, time.perf_counter()
-        for _ in range(40):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(n_train):
-                step(k)
-            drain()
-            torch.cuda.synchronize()
-            cur = (time.perf_counter() - t0) / n_train
-            settle["trains"] += 1
-            stop = prev is not None and abs(cur - prev) <= 0.01 * prev and (time.perf_counter() - t_begin) >= 0.05
-            settle["last_two_ms_per_step"] = [round(1e3 * x, 4) for x in (prev if prev is not None else cur, cur)]
-            prev = cur
-            if multi:                                            # every rank must leave the loop together
-                tt = torch.tensor([0 if stop else 1], dtype=torch.int32, device=ctl_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                stop = int(tt.item()) == 0
-            if stop:
-                break
-        settle["ms"] = round(1e3 * (time.perf_counter() - t_begin), 1)
-        fence()
-
-    for k in range(args.warmup):
-        step(k)
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    drain()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    channels = 4 if (not multi or mode["p2p"]) else a2a_channels          # bytes per pixel the chosen plan's launches store
-    # ---- dominant kernel: average launch duration, HIP events on the launch stream.  At N=1 the timed region IS a train of
-    #      these launches on this stream, so two events around a train of them give the average over every launch (what
-    #      rocprofv3's per-kernel average of the same command shows); at N>1 the region also waits for slots, so the kernel is
-    #      timed on a train of its own ----
-    fence()
-    n_train = max(20, min(args.steps, 2000)) if not multi else min(max(20, args.steps), 200)
-    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(min(10, n_train)):
-        render_step(0)
-    ev_a.record()
-    for _ in range(n_train):
-        render_step(0)
-    ev_b.record()
-    torch.cuda.synchronize()
-    kernel_ms = ev_a.elapsed_time(ev_b) / n_train
-    launch_pixels = w * h if not multi else frames_per_step * plan.pixels_of(rank)
-
-    # one more (untimed) group of steps; EVERY owner checks the frames it reassembled against the rows the reference itself
-    # rendered (tests/golden, fixtures) or, for a frame size without fixtures, a few rows of the C restatement
-    fence()
-    frames.zero_()
-    if p2p and i_own and lib.rt_memset_device(dev_index, my_buf, 0, 2 * every * frame_bytes) != 0:
-        raise SystemExit("bench.py: rt_memset_device: " + lib.rt_last_error().decode())
-    fence()                                                        # nobody stores into a buffer that is still being cleared
-    for k in range(every):                                         # one whole group, so every frame slot is rewritten
-        step(k)
-    drain()
-    fence()
-
-    def reassembled(j):
-        if not mode["p2p"]:
-            return frames[j].cpu().numpy()
-        host = np.empty((h, w, 4), dtype=np.uint8)
-        if lib.rt_copy_to_host(dev_index, host.ctypes.data, my_buf + (group["last_slot"] * every + j) * frame_bytes, frame_bytes) != 0:
-            raise SystemExit("bench.py: rt_copy_to_host: " + lib.rt_last_error().decode())
-        return host
-
-    max_lsb = 0
-    if i_own:
-        for j in range(every):
-            fr = reassembled(j)
-            max_lsb = max(max_lsb, worst_lsb(fr))
-            if not (fr[..., 3] == 255).all():
-                max_lsb = 255                                          # a row nobody wrote
-            del fr
-    if world > 1:
-        t = torch.tensor([int(max_lsb)], dtype=torch.int64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        max_lsb = int(t.item())
-    parity_ok = max_lsb <= 1          # tolerance: 1 LSB per channel (SURVEY 8(c))
+    single_default = single
+    out, parity_ok, max_lsb = run(single_default)
+    # cfg3 on several GPUs: the batch line above is what BASELINE's metric scales weakly; north_star's own form - ONE 3840x2160 frame
+    # row-tiled over the ranks, whole on rank 0 - is measured as well and rides in the same JSON line
+    if world > 1 and args.config == "cfg3" and not single_default and os.environ.get("RT_BENCH_NO_SINGLE_FRAME") != "1":
+        out2, ok2, lsb2 = run(True)
+        parity_ok, max_lsb = parity_ok and ok2, max(max_lsb, lsb2)
+        if rank == 0:
+            out["single_frame"] = {k: out2[k] for k in ("value", "unit", "ms_per_step", "scaling", "max_lsb_vs_reference_rows", "parity_ok", "n1_reference", "efficiency_vs_n1", "exchange") if k in out2}
+            out["single_frame"]["workload"] = out2["config"]["workload"]
+            for k in ("plan_note", "plan_calibration_ms_per_step"):
+                if k in out2["config"]:
+                    out["single_frame"][k] = out2["config"][k]
     if rank == 0:
-        # work counters from the instrumented variant (untimed)
-        cnt_frame = frame if i_own and frames.shape[1] == h else torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-        st = renderer.render_tiles(w, h, cnt_frame.data_ptr(), whole, stream=stream, flags=flags | rt_host.RT_FLAG_COUNT, want_stats=True)
-        rays_pp, shadow_pp, tests_pp = st.rays / st.pixels, st.shadow_rays / st.pixels, st.sphere_tests / st.pixels
-        total_pixels = w * h * frames_per_step * args.steps
-        value = total_pixels / elapsed / 1e6
-        flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
-        algo_bytes = float(channels) * launch_pixels        # what one launch stores: RGBA8, or RGB24 bands at N>1
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic and executed FP64 instructions per launch: PMC passes over a short child run of this same command
-        traffic, traffic_src, fp64_measured = None, None, None
-        pmc, pmc_note = (None, "not collected (--no-pmc)") if (args.no_pmc or multi or os.environ.get("RT_BENCH_CHILD") == "1") else pmc_passes(
-            ["--config", args.config] + (["--scene", scene_name] if args.scene else [])
-            + (["--width", str(w)] if args.width else []) + (["--height", str(h)] if args.height else []) + (["--strict-fp"] if args.strict_fp else []))
-        if pmc:
-            traffic = pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0          # KiB -> bytes; FETCH_SIZE counts half (MI355X_MICROARCH.md, HBM)
-            traffic_src = "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) over a 12-step child run of this command; FETCH_SIZE doubled (gfx950)"
-            fl = (2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] + pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"]) * 64.0
-            fp64_measured = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "salu_insts_per_launch": pmc["SQ_INSTS_SALU"],
-                             "fma_f64": pmc["SQ_INSTS_VALU_FMA_F64"], "add_f64": pmc["SQ_INSTS_VALU_ADD_F64"], "mul_f64": pmc["SQ_INSTS_VALU_MUL_F64"],
-                             "trans_f64": pmc["SQ_INSTS_VALU_TRANS_F64"], "flop_per_launch_upper_bound": fl,
-                             "achieved": round(fl / (kernel_ms * 1e-3) / 1e12, 3), "frac": round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
-                             "note": "wave-instructions x 64 lanes (an upper bound: assumes a full exec mask), FMA = 2 flop; this run's counters, this run's kernel_ms"}
-            if "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"] > 0:
-                # issue fractions: cycles in which a vector / scalar / any instruction was issued, per busy SQ cycle (SQ_ACTIVE_INST_* are
-                # summed over an SQ's SIMDs, so VALU is also given per SIMD) and per resident wave-cycle
-                fp64_measured["issue"] = {"valu_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"], 4),
-                                          "valu_per_busy_cycle_per_simd": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"] / 4.0, 4),
-                                          "scalar_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_SCA"] / pmc["SQ_BUSY_CYCLES"], 4),
-                                          "any_per_wave_cycle": round(pmc["SQ_ACTIVE_INST_ANY"] / pmc["SQ_WAVE_CYCLES"], 4) if pmc.get("SQ_WAVE_CYCLES") else None,
-                                          "counters": {k: pmc[k] for k in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY") if k in pmc}}
-            elif "issue_note" in pmc:
-                fp64_measured["issue"] = {"note": pmc["issue_note"]}
-        else:
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            key = "%s_%dx%d" % (scene_name, w, h)
-            if os.path.exists(tpath) and world == 1:
-                tj = json.load(open(tpath))
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-                    traffic_src = "REPLAYED from profiles/traffic.json (%s): %s" % (tj[key].get("source", "committed profile"), pmc_note)
-                    if "fp64" in tj[key]:
-                        fl = tj[key]["fp64"]["flop_per_launch_upper_bound"]
-                        fp64_measured = dict(tj[key]["fp64"], achieved=round(fl / (kernel_ms * 1e-3) / 1e12, 3),
-                                             frac=round(fl / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, 4),
-                                             note="counters REPLAYED from profiles/traffic.json, this run's kernel_ms")
-        if not multi:
-            how = "one launch per frame" + ("; consecutive frames alternate between two HIP streams and two frame buffers" if two_streams else "")
-        elif mode["p2p"]:
-            how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank whose stores go straight into the "
-                   "frame buffer of the rank that owns each frame (peer-mapped over xGMI, RGBA8, rows in place): no data collective, no "
-                   "de-interleave; one all_reduce per %d steps is the barrier"
-                   % ("ONE frame, whole on rank 0" if single else "a batch of %d frames" % world, TILE_ROWS, world, every))
-        else:
-            how = ("a step = %s: interleaved %d-row tiles over %d ranks, one launch per rank, ONE %s (RCCL over xGMI) "
-                   "reassembles %s (bands travel as %s), de-interleave to RGBA8 in HBM; the bands of %d consecutive steps share one "
-                   "collective, which overlaps the renders of the next %d steps"
-                   % ("ONE frame" if single else "a batch of %d frames" % world, TILE_ROWS, world, "gather to rank 0" if single else "all-to-all",
-                      "the frame on rank 0" if single else "frame f on rank f", "RGB24, alpha restored on arrival" if channels == 3 else "RGBA8", every, every))
-        # the store roofline as this box delivers it (SURVEY 8(d): quote a measured fill next to the nominal peak): a 2 GiB
-        # torch fill, best of 5, on the launch stream
-        fill_gbs = None
-        if not multi:
-            try:
-                big = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
-                best = None
-                for _ in range(6):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    big.fill_(7)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1)
-                    best = ms if best is None else min(best, ms)
-                fill_gbs = round((2 << 30) / (best * 1e-3) / 1e9, 1)
-                del big
-            except Exception:      # noqa: BLE001  (a small box: the nominal peak stands alone)
-                fill_gbs = None
-        model_tf = flops_pp * launch_pixels / (kernel_ms * 1e-3) / 1e12
-        out = {
-            "metric": "Mpixel/s", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (single and multi) else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s scene (%d spheres, %d lights, depth %d, supersample %d) at %dx%d; SCENE, CAMERA AND LAUNCH TABLE RESIDENT (a static frame rendered again and again: "
-                                   "cold_frame / new_camera_every_step are the other cases); %s" % (
-                args.config if (scene_name, w, h) == CONFIGS[args.config][:3] else "custom", scene_name, len(scene["objects"]), len(scene["lights"]),
-                scene["segs"], ss, w, h, how),
-                "kernel": "strict (no FMA)" if args.strict_fp else "fma", "frames_per_step": frames_per_step,
-                "pixels_per_gpu_per_step": (w * h * frames_per_step) // world if multi else w * h,
-                "steady_state_warmup": settle,
-                **({"REHEARSAL": "all ranks on one GPU, gloo through host memory - not a measurement"} if rehearse else {}),
-                **({"FORCED_EXCHANGE": "the N>1 plan run by ONE rank (1-rank RCCL collective = self copy): the plan's own overhead, not the headline"} if force else {})},
-            "mray_per_s": round(value * rays_pp, 2), "mshadow_per_s": round(value * shadow_pp, 2),
-            "rays_per_pixel": round(rays_pp, 4), "shadow_rays_per_pixel": round(shadow_pp, 4), "sphere_tests_per_pixel": round(tests_pp, 3),
-            "max_lsb_vs_reference_rows": max_lsb, "parity_ok": parity_ok, "parity_checked_against": check_source,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "rt_trace", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "measured_fill_GBs": fill_gbs, "frac_of_measured_fill": (round(achieved / fill_gbs, 6) if fill_gbs else None),
-                         "binding_bound": "fp64 vector issue under divergence (fp64_valu.measured), not HBM: the store roofline is the one the metric names",
-                         "note": "%d B per output pixel (one %s store); the path is FP64-VALU bound, see fp64_valu" % (channels, "RGBA8" if channels == 4 else "RGB24")},
-            "fp64_valu": {"peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "measured": fp64_measured,
-                          "reference_work_rate": {"flop_per_pixel": round(flops_pp, 1), "tflop_per_s_of_reference_work": round(model_tf, 3),
-                                                  "note": "NOT a utilisation: the REFERENCE's algorithmic operation count (SURVEY 8(d): 15/test + 120/ray + 60/shadow ray) per pixel x "
-                                                          "this kernel's pixel rate; the product kernel does not execute those operations (anchored tests are 4, not 10; sky workgroups, "
-                                                          "most floor blocks' shadow scans and the culled tests are never executed) - `measured` is what it executes"},
-                          "kernel_mpixel_per_s": round(launch_pixels / (kernel_ms * 1e-3) / 1e6, 1)},
-        }
-        if p2p_note:
-            out["config"]["plan_note"] = p2p_note
-        if calibration:
-            out["config"]["plan_calibration_ms_per_step"] = calibration
-        if multi and mode["p2p"]:
-            out["exchange"] = {"plan": "peer stores (rt_render_scatter_device through IPC-mapped frame buffers)", "collective": "all_reduce of one int per group (barrier)",
-                               "bytes_stored_remotely_per_rank_per_step": sum(1 for g in owners if g != rank) * plan.pixels_of(rank) * 4, "steps_per_barrier": every}
-        elif multi:
-            out["exchange"] = {"plan": "exchange", "collective": "gather to rank 0" if single else "all_to_all_single",
-                               "bytes_sent_per_rank_per_step": plan.band_bytes if single else (world - 1) * plan.band_bytes,
-                               "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
-                               "steps_per_collective": every}
-        if world == 1 and not args.no_cold and not args.strict_fp and os.environ.get("RT_BENCH_CHILD") != "1" and w * h <= 7680 * 4320:
-            try:
-                out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(64, min(args.steps, 512))))
-            except Exception as e:   # noqa: BLE001  (the headline must still be reported)
-                out["cold_frame"] = {"note": "failed: %r" % (e,)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(scene_name, w, h)
-            except Exception as e:   # the GPU number must still be reported
-                out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    renderer.close()
-    if p2p:
-        fence()
-        for g, q in peer_buf.items():
-            if g != rank:
-                lib.rt_ipc_close(dev_index, q)
-        fence()
-        if my_buf:
-            lib.rt_free_device(dev_index, my_buf)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -993,6 +993,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows > (1ull << 24)) return fail(RT_ERR_INVALID, "too many rows in one call");
   if ((uint64_t)tiles->n_tiles * tiles->tile_rows * w >= (1ull << 32)) return fail(RT_ERR_INVALID, "a call may cover at most 2^32 - 1 pixels per frame");
   if ((flags & RT_FLAG_RGB24) && (w & 3u)) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 needs a frame width that is a multiple of 4 (got %u)", w);
+  if ((flags & (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY)) == (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY) || ((flags & (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY)) && (flags & RT_FLAG_COUNT)))
+    return fail(RT_ERR_INVALID, "RT_FLAG_NO_SKY and RT_FLAG_SKY_ONLY exclude each other and RT_FLAG_COUNT");
   int rc = ensure_device(s->device);
   if (rc) return rc;
   device_state &D = G.dev[s->device];
@@ -1012,7 +1014,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
 
   const rt_scene_header &hd = s->hd;
   const uint32_t ss = ss_override ? ss_override : hd.supersample;
-  if (ss > 2u) return render_supersampled(s, ss, w, h, tiles, n_frames, d_out, frame_stride_bytes, d_frames, stream, flags, stats);
+  if (ss > 2u) {
+    // (3x3 / 4x4 supersampling filters whole blocks of samples: a NO_SKY call stores every pixel, a SKY_ONLY call none)
+    if (flags & RT_FLAG_SKY_ONLY) { if (stats) memset(stats, 0, sizeof *stats); return RT_OK; }
+    return render_supersampled(s, ss, w, h, tiles, n_frames, d_out, frame_stride_bytes, d_frames, stream, flags & ~(uint32_t)RT_FLAG_NO_SKY, stats);
+  }
   const bool ss2 = ss == 2u;
   const bool count = (flags & RT_FLAG_COUNT) != 0;
   // Which kernel.  The product (FMA) kernel unless the caller asks for the strict one - or the scene itself sits on an exact
@@ -1104,6 +1110,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   L.n_frames = n_frames;
   L.frame_stride = frame_stride_bytes / 4u;
   L.rgb24 = (flags & RT_FLAG_RGB24) ? 1u : 0u;
+  L.sky_part = (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u);
   L.scatter = d_frames ? 1u : 0u;
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
@@ -1130,7 +1137,9 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   const uint32_t *marks_read = nullptr;                 // stats: where this launch's mark count can be read afterwards
   uint64_t centre_items = 0;
   bool retraced_all = false;
-  if (strict_main) {
+  if (strict_main && (flags & RT_FLAG_SKY_ONLY)) {
+    // (the strict kernels know no sky blocks: the RT_FLAG_NO_SKY calls of such a launch store every pixel, this one none)
+  } else if (strict_main) {
     std::lock_guard<std::mutex> lk(s->launch_mu);
     if (rt_scene_dev::stage_slot *cam = s->cam_pending) {          // the camera has moved: its block first
       hipError_t e = (hipError_t)rt_launch_small_copy(s->d_cam, cam->h, s->cam_bytes_used, nullptr, nullptr, 0u, stream);
@@ -1197,7 +1206,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     if (!ss2 && (w & 1u)) { F.centre_col = (w - 1u) / 2u; centre_items += (uint64_t)tiles->n_tiles * tiles->tile_rows * n_frames; }
     const bool retrace_all = RT_TEST_ENV("RT_EXACT_ALL") != nullptr && !no_fixup;
     const uint32_t known = test_marks ? 0u : known_value(ms->h_known, s->cam_gen);        // 0: not known (yet); else the frame's mark count + 1
-    const bool need = !no_fixup && (known != 1u || centre_items != 0 || retrace_all);
+    const bool need = !no_fixup && !(flags & RT_FLAG_SKY_ONLY) && (known != 1u || centre_items != 0 || retrace_all);     // (a sky-only launch traces nothing; the centre lines belong to the calls that trace)
     if (err == 0 && need) {
       bind_kernel(F, true);                             // the scene in its own order, every sphere in the loops, the reference's own miss colour
       F.marks_known = test_marks ? nullptr : (unsigned long long *)ms->h_known;
@@ -1653,7 +1662,12 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
         if (e == hipSuccess) e = hipEventCreate(&ev1[g]);
         if (e == hipSuccess) e = hipEventRecord(ev0[g], G.dev[g].stream);
         if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e)); break; }
-        rc = rt_render_scatter_device(scenes[g], w, h, &t, 1u, root_frame, nullptr, kflags, nullptr);
+        // (the sky blocks of the whole frame are GPU 0's own work, below: the other GPUs do not send theirs over the links)
+        rc = rt_render_scatter_device(scenes[g], w, h, &t, 1u, root_frame, nullptr, kflags | (g ? RT_FLAG_NO_SKY : 0u), nullptr);
+        if (!rc && g == 0) {
+          rt_tiles whole = {h, 0u, 1u, 1u};
+          rc = rt_render_scatter_device(scenes[0], w, h, &whole, 1u, root_frame, nullptr, kflags | RT_FLAG_SKY_ONLY, nullptr);
+        }
         if (!rc && (e = hipEventRecord(ev1[g], G.dev[g].stream)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "timing events on device %d: %s", g, hipGetErrorString(e));
       }
       // every GPU's stores have landed in GPU 0's frame once its stream is drained; then the copy-out

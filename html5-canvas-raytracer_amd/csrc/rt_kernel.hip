@@ -570,7 +570,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   [[maybe_unused]] frame<REFRACT> stack[FOLD_FORWARD ? 1 : RT_MAX_SEGS];
   // product general kernel: nodes with BOTH a reflection and a refraction child are parked here while their
   // reflection subtree is traced (everything else needs no stack)
-  [[maybe_unused]] park parked[(FOLD_FORWARD && REFRACT) ? RT_MAX_SEGS : 1];
+#ifndef RT_AB_PARK_DEPTH
+#define RT_AB_PARK_DEPTH RT_MAX_SEGS
+#endif
+  [[maybe_unused]] park parked[(FOLD_FORWARD && REFRACT) ? RT_AB_PARK_DEPTH : 1];
   [[maybe_unused]] int sp = 0;
   [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
@@ -700,7 +703,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         bool scanned = false;
 #if !RT_STRICT
         if constexpr (GRID) {
-          if (L.bounce_table != nullptr) {
+          if (rt_cold_args()->bounce_table != nullptr) {
             // Many spheres: a bounced ray starts ON the sphere it just hit (`hcode` still names it) and its direction
             // falls in one cell of a cube map.  The host stored, per (sphere, cell), the bit set of the spheres that
             // ANY ray leaving that sphere's ball in ANY direction of that cell can meet (conservative: angle between
@@ -724,7 +727,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               uint32_t distinct = 0;
               while (todo) {
                 const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
-                cand |= rt_load_word32(L.bounce_table, k0 * words + wd);
+                cand |= rt_load_word32(rt_cold_args()->bounce_table, k0 * words + wd);
                 todo &= ~__ballot(key == k0);
                 if (++distinct == 16u && todo) {           // a wave whose rays fan out over many cells: scan everything
                   cand = (wd + 1u == words && (NLOOP & 63u)) ? ((1ull << (NLOOP & 63u)) - 1ull) : ~0ull;
@@ -884,7 +887,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           // the index comes out of the fixed-point sum (u, v in [0, 1]; widths and heights <= 16384)
           RT_XY_INDEX(xu, xv)
           const uint32_t xi = min(iu, td.width - 1u), yi = min(iv, td.height - 1u);   // memory safety only; u,v <= 1
-          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+          const uint32_t texel = *(const uint32_t *)(rt_cold_args()->texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
           col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
           col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
         } else if (kind == RT_SAMPLER_CHECKER) {
@@ -931,7 +934,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #else
         if (a1 > 0.0 || a2 > 0.0) {
 #endif
+#if RT_STRICT
           double li = L.light_intensity;                               // shared across lights (q2)
+#else
+          double li = rt_cold_args()->light_intensity;                 // shared across lights (q2); read where it is used (two scalar registers less across the loop)
+#endif
 #if !RT_STRICT
           [[maybe_unused]] uint32_t smask = ~0u;
           if constexpr (!COUNT) { if (primary_node) smask = rt_entry_shadow_masks(L); }
@@ -1038,7 +1045,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             if constexpr (!COUNT) no_occluder = primary_node && k < 2u && ((smask >> (16u * k)) & 0xffffu) == 0u;
             if (no_occluder) {
             } else
-            if (GRID && L.shadow_grid != nullptr && li != 0.0) {
+            if (GRID && rt_cold_args()->shadow_grid != nullptr && li != 0.0) {
               // Many spheres: cull the scan with the light's grid.  The host cut light k's view of the scene
               // (projective coordinates x'/z', y'/z' in a frame looking from the light at the scene) into
               // RT_SGRID x RT_SGRID cells and stored, per cell, the bit set of spheres whose conservative rectangle
@@ -1046,7 +1053,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               // ray lies on the line from the light through its hit point, so only the spheres of that point's cell
               // can block it.  The wave tests the UNION over its active lanes: the distinct cells are walked with
               // readlane/ballot (correct under divergence: it never relies on inactive lanes), typically 1-4 of them.
-              const double __attribute__((address_space(4))) *gh = (const double __attribute__((address_space(4))) *)L.shadow_grid + 16u * k;
+              const void *const sgrid = rt_cold_args()->shadow_grid;     // (read where it is used: the many-sphere kernels have no scalar register to spare)
+              const double __attribute__((address_space(4))) *gh = (const double __attribute__((address_space(4))) *)sgrid + 16u * k;
               const v3 vv = mk(-sraw.x, -sraw.y, -sraw.z);                                   // light -> hit point
               const double vx = gh[0] * vv.x + gh[1] * vv.y + gh[2] * vv.z, vy = gh[3] * vv.x + gh[4] * vv.y + gh[5] * vv.z;
               const double vz = gh[6] * vv.x + gh[7] * vv.y + gh[8] * vv.z;
@@ -1061,7 +1069,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
                 unsigned long long cand = 0ull, todo = __ballot(true);
                 while (todo) {
                   const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)__builtin_ctzll(todo));
-                  cand |= rt_load_word32(L.shadow_grid, cells_at + c0 * words + wd);
+                  cand |= rt_load_word32(sgrid, cells_at + c0 * words + wd);
                   todo &= ~__ballot(cell == c0);
                 }
                 while (cand) {
@@ -1369,12 +1377,6 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t image_vec = image_words >> 1;                                     // 16-byte units (GRID: the image is whole units)
   [[maybe_unused]] rt_u4 piece[RT_STAGE_PIECES];
   [[maybe_unused]] double stage0 = 0.0;
-#if !RT_STRICT && defined(RT_AB_ENTRY_FIRST)
-  // (experiment: the table entry first - a workgroup without rows, or a sky workgroup, issues no staging load at all)
-  const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
-  if (P0.rows_valid == 0u) return;
-  if (!P0.sky) {
-#endif
   if constexpr (GRID) {
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
@@ -1382,9 +1384,6 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   } else {
     stage0 = (tid < image_words) ? image[tid] : 0.0;
   }
-#if !RT_STRICT && defined(RT_AB_ENTRY_FIRST)
-  }
-#endif
   const rt_mtl *mtl = (const rt_mtl *)lds_raw;
   const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
   const rt_geom *cull_lds = (const rt_geom *)(lds_raw + mtl_words + tex_words);
@@ -1398,14 +1397,15 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
-#if RT_STRICT || !defined(RT_AB_ENTRY_FIRST)
   const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
-#endif
 #if !RT_STRICT
   // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
   // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last
   // entry are zero (rt_tables_gpu.hip)
   if (P0.rows_valid == 0u) return;
+  // RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY (a frame assembled from several GPUs' tiles: the OWNER fills the sky blocks of the whole frame from
+  // its own table, the others do not send them over the links): this workgroup's kind of block is not this launch's
+  if (L.sky_part != 0u && ((L.sky_part == 1u) == P0.sky)) return;
 #endif
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};

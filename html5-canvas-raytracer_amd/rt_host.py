@@ -31,6 +31,8 @@ SAMPLER_COLOR, SAMPLER_TEXTURE, SAMPLER_CHECKER, SAMPLER_STARS = 0, 1, 2, 3
 RT_FLAG_COUNT = 1
 RT_FLAG_STRICT_FP = 2
 RT_FLAG_RGB24 = 4        # device entry points: 3 bytes per pixel, the constant alpha stays home (include/rt_hip.h)
+RT_FLAG_NO_SKY = 8       # blocks that can only show the constant background are not stored (the frame's owner stores them: RT_FLAG_SKY_ONLY)
+RT_FLAG_SKY_ONLY = 16
 
 
 # --------------------------------------------------------------------------- scenes

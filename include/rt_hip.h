@@ -141,10 +141,18 @@ enum {
   RT_FLAG_NONE = 0,
   RT_FLAG_COUNT = 1,        /* run the counting variant and fill rays/shadow_rays/sphere_tests */
   RT_FLAG_STRICT_FP = 2,    /* no FMA contraction: operation-for-operation with the JS expression trees */
-  RT_FLAG_RGB24 = 4         /* device entry points only: store 3 bytes per pixel (R,G,B, rows packed, w*3 bytes each)
+  RT_FLAG_RGB24 = 4,        /* device entry points only: store 3 bytes per pixel (R,G,B, rows packed, w*3 bytes each)
                              * instead of RGBA8.  The alpha byte is the constant 255 in the reference (main.js:198),
                              * so a band that is about to cross an xGMI link does not carry it; the receiving side
                              * restores it with rt_deinterleave_rgb24_device.  Needs w % 4 == 0. */
+  RT_FLAG_NO_SKY = 8,       /* device entry points: blocks of 32 x 8 pixels in which nothing but a constant background can show (the
+                             * reference's skybox with a plain colour, or the miss colour of main.js:231 - half of the headline frame) are
+                             * NOT stored.  For a frame assembled from several GPUs' tiles in ONE buffer (rt_render_scatter_device into the
+                             * owner's frame over xGMI): the senders leave the sky out ... */
+  RT_FLAG_SKY_ONLY = 16     /* ... and the frame's owner stores exactly those blocks, of whatever tiles the call names (the whole frame),
+                             * from its own table: the two kinds of call together store every pixel once, and about half of the
+                             * headline's pixels never cross a link.  Scenes without a constant background: RT_FLAG_NO_SKY leaves nothing
+                             * out and RT_FLAG_SKY_ONLY stores nothing.  Not with RT_FLAG_COUNT. */
 };
 
 typedef struct rt_scene_dev rt_scene_dev; /* opaque: a scene resident in one GPU's HBM */

@@ -49,6 +49,12 @@ def test_batch_mode_exchange_plan():
     assert out["exchange"]["steps_per_collective"] == 4
     assert "plan_calibration_ms_per_step" not in out["config"]
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    # the same run also measures ONE frame per step row-tiled over the ranks (strong scaling), and both carry what one GPU does alone
+    one = out["single_frame"]
+    assert one["scaling"] == "strong" and one["parity_ok"] is True and one["value"] > 0
+    assert out["n1_reference"]["mpixel_per_s"] > 0 and one["n1_reference"]["mpixel_per_s"] > 0
+    assert abs(out["efficiency_vs_n1"] - out["value"] / (2 * out["n1_reference"]["mpixel_per_s"])) < 1e-3
+    assert abs(one["efficiency_vs_n1"] - one["value"] / (2 * one["n1_reference"]["mpixel_per_s"])) < 1e-3
 
 
 def test_batch_mode_peer_store_plan():
@@ -57,7 +63,14 @@ def test_batch_mode_peer_store_plan():
     out, _ = run_bench(2, RT_BENCH_P2P="1")
     assert out["exchange"]["plan"].startswith("peer stores")
     assert "plan_note" not in out["config"]
-    assert out["exchange"]["bytes_stored_remotely_per_rank_per_step"] > 0
+    ex = out["exchange"]
+    assert ex["bytes_stored_remotely_per_rank_per_step"] > 0
+    # the senders leave the constant-background blocks out: about half of the headline frame never crosses a link
+    assert 0.4 < ex["sky_fraction_of_this_ranks_blocks"] < 0.6
+    assert ex["bytes_stored_remotely_per_rank_per_step"] < 0.62 * ex["bytes_stored_remotely_per_rank_per_step_with_the_sky"]
+    assert out["single_frame"]["exchange"]["plan"].startswith("peer stores")
+    sent, _ = run_bench(2, RT_BENCH_P2P="1", RT_BENCH_SEND_SKY="1", RT_BENCH_NO_SINGLE_FRAME="1")
+    assert sent["exchange"]["bytes_stored_remotely_per_rank_per_step"] == ex["bytes_stored_remotely_per_rank_per_step_with_the_sky"]
 
 
 def test_peer_store_failure_falls_back_to_the_exchange_plan():

@@ -1246,3 +1246,41 @@ def test_a_moved_camera_renders_what_a_fresh_upload_renders(lib, scene, w, h):
         sc["camera"] = _look_at_camera([cam0[0] - 0.9 * k, cam0[1] + 0.1, cam0[2] + 0.4 * k], [0.0, 1.0 + 0.2 * k, 0.0])
         rgba, st = rt_host.render(w, h, sc)
         assert bytes(rgba) == gpu_frame(lib, rt_host.flatten_scene(sc), w, h, FAST), (scene, "rt_render", k)
+
+
+@pytest.mark.parametrize("scene,w,h,G,tile_rows", [("h8", 640, 360, 3, 16), ("h8", 131, 77, 2, 8), ("cfg1", 256, 256, 4, 16), ("cfg2", 480, 270, 3, 8),
+                                                    ("default14", 320, 180, 2, 16), ("lcg64", 256, 128, 4, 8), ("lcg64_ss3", 96, 64, 2, 8), ("default14_stars", 160, 90, 2, 8)])
+def test_the_owner_fills_the_sky_and_the_senders_leave_it_out(lib, scene, w, h, G, tile_rows):
+    """RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY: a frame assembled in ONE buffer from G ranks' interleaved tiles (peer stores over xGMI on a
+    real node; here G scatter calls into one buffer).  The senders leave out the blocks in which only the constant background can show,
+    the frame's owner stores exactly those blocks of the WHOLE frame from its own launch table: together every pixel once, the
+    bytes of the plain frame; for the headline's scene about half of the pixels never cross a link.  Scenes without a constant
+    background (a textured / starry sky), strict-kernel launches and 3x3 supersampling: the senders store everything, the owner's
+    call nothing."""
+    import shard
+    sc = rt_host.load_scene(scene)
+    blob = rt_host.flatten_scene(sc)
+    want = gpu_frame(lib, blob, w, h, FAST)
+    n = w * h * 4
+    plan = shard.TilePlan(w, h, tile_rows, G)
+    d = lib.rt_alloc_device(0, n)
+    r = rt_host.Renderer(blob, 0, lib)
+    try:
+        for flags in (FAST, STRICT):
+            assert lib.rt_memset_device(0, d, 0, n) == 0
+            for g in range(G):
+                r.render_scatter(w, h, [d], rt_host.RtTiles(*plan.rt_tiles(g)), flags=flags | rt_host.RT_FLAG_NO_SKY, want_stats=True)
+            host = C.create_string_buffer(n)
+            assert lib.rt_copy_to_host(0, host, d, n) == 0
+            a = np.frombuffer(host.raw, dtype=np.uint8).reshape(h, w, 4)
+            left_out = int((a[..., 3] == 0).sum())                # pixels nobody stored yet
+            r.render_scatter(w, h, [d], rt_host.RtTiles(h, 0, 1, 1), flags=flags | rt_host.RT_FLAG_SKY_ONLY, want_stats=True)
+            assert lib.rt_copy_to_host(0, host, d, n) == 0
+            assert host.raw == (want if flags == FAST else gpu_frame(lib, blob, w, h, STRICT)), (scene, flags)
+            if flags == FAST and scene in ("h8", "cfg1", "lcg64"):
+                assert left_out > (0.15 if w >= 256 else 0.05) * w * h, (scene, left_out)       # a constant background: a good part of the frame stays home
+            if flags == STRICT or scene in ("default14_stars", "lcg64_ss3"):
+                assert left_out == 0, (scene, flags, left_out)
+    finally:
+        r.close()
+        lib.rt_free_device(0, d)
