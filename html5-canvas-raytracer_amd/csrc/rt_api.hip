@@ -1513,12 +1513,23 @@ int ensure_frame(int device, size_t bytes) {
 namespace {
 int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats,
                    uint32_t want_bands, rt_band_callback on_band, void *user);
-int g_last_plan = 0;      // how the last rt_render put its frame together: 0 one GPU, 1 peer stores, 2 ncclGather (or its emulation)
+int g_last_plan = 0;      // how the last rt_render put its frame together: 0 one GPU (banded copy-out), 1 peer stores, 2 ncclGather (or its emulation), 3 one GPU storing into the pinned frame
+int g_direct_stores = 1;  // one GPU: store straight into a pinned (mapped) caller buffer: 0 never, 1 frames below 8 MiB, 2 always (rt_render_options)
+int g_copy_bands = 4;     // one GPU, copy-out plan: bands whose copy-out overlaps the next band's render (rt_render_options)
 }  // namespace
 
 #ifdef RT_TESTING
 extern "C" int rt_test_last_plan(void) { return g_last_plan; }
 #endif
+
+extern "C" int rt_render_options(int direct_stores, uint32_t copy_bands) {
+  if (copy_bands == 0 || copy_bands > 64u) return fail(RT_ERR_INVALID, "copy_bands %u not in 1..64", copy_bands);
+  if (direct_stores < 0 || direct_stores > 2) return fail(RT_ERR_INVALID, "direct_stores %d not in 0..2", direct_stores);
+  std::lock_guard<std::mutex> lk(G.mu);
+  g_direct_stores = direct_stores;
+  g_copy_bands = (int)copy_bands;
+  return RT_OK;
+}
 
 extern "C" int rt_render(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8_t *out_rgba, uint32_t flags, rt_stats *stats) {
   return render_to_host(blob, bytes, w, h, out_rgba, flags, stats, 0u, nullptr, nullptr);
@@ -1555,15 +1566,76 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
     rt_scene_dev *s = nullptr;
     if ((rc = scene_for(0, blob, bytes, &s))) return rc;
     device_state &D = G.dev[0];
-    rc = ensure_frame(0, frame_bytes);                             // (makes device 0 current: a previous multi-GPU call may have left another one)
+    rc = ensure_device(0);                                          // (makes device 0 current: a previous multi-GPU call may have left another one)
+    const bool count = (flags & RT_FLAG_COUNT) != 0;
+    // Where the frame goes.  A buffer from rt_alloc_pinned (what the N-API layer hands in: the ImageData.data of main.js:83,
+    // 195-200) is mapped into the GPU's address space: the kernel can store its pixels STRAIGHT into it over PCIe - 128-byte lines,
+    // posted writes - with no staging frame in HBM, no copy engine and no band bookkeeping; the call then takes
+    // ~max(kernel, frame bytes / PCIe).  Measured (r03_ab_log.md section 4) that is what the banded copy-out below takes as well -
+    // the link, ~50-55 GB/s here, is the bound either way - and the copy engine is 2-7 % ahead for frames of 8 MiB and more, the
+    // direct stores 3 % for smaller ones: the default follows the measurement.  Pageable memory always takes the copy-out.
+    void *d_direct = nullptr;
+    if (!rc && (g_direct_stores == 2 || (g_direct_stores == 1 && frame_bytes < (8u << 20)))) {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, out_rgba) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) d_direct = attr.devicePointer;
+      else (void)hipGetLastError();
+    }
+    if (d_direct && !rc) {
+      // (rt_render_progressive: one launch per band, announced when its event has passed)
+      const uint32_t nb = count ? 1u : (want_bands ? want_bands : 1u);
+      const uint32_t rows_per = ((h + nb - 1) / nb + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+      rt_stats st;
+      memset(&st, 0, sizeof st);
+      if (nb == 1) {
+        rt_tiles whole = {h, 0, 1, 1};
+        rc = rt_render_tiles_device(s, w, h, &whole, d_direct, nullptr, flags, &st);       // (waits: stats)
+        if (!rc && on_band) on_band(user, 0u, h);
+      } else {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<hipEvent_t> done(nb, nullptr);
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventRecord(e0, D.stream);
+        for (uint32_t b = 0; b < nb && !rc && e == hipSuccess && b * rows_per < h; b++) {
+          rt_tiles band = {rows_per, b, 1, 1};
+          rc = rt_render_tiles_device(s, w, h, &band, (uint8_t *)d_direct + (size_t)b * rows_per * w * 4u, nullptr, flags, nullptr);
+          if (rc) break;
+          e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+          if (e == hipSuccess) e = hipEventRecord(done[b], D.stream);
+        }
+        if (e == hipSuccess && !rc) e = hipEventRecord(e1, D.stream);
+        for (uint32_t b = 0; b < nb && e == hipSuccess && !rc && done[b]; b++) {
+          e = hipEventSynchronize(done[b]);
+          const uint32_t r0 = b * rows_per;
+          if (e == hipSuccess) on_band(user, r0, (r0 + rows_per <= h) ? rows_per : h - r0);
+        }
+        { const hipError_t e2 = hipStreamSynchronize(D.stream); if (e == hipSuccess) e = e2; }      // (nothing may still be storing into the caller's buffer)
+        if (e == hipSuccess && !rc) { float ms = 0.f; e = hipEventElapsedTime(&ms, e0, e1); st.kernel_ms = ms; }
+        if (e != hipSuccess && !rc) rc = fail(RT_ERR_DEVICE, "banded render into the pinned frame: %s", hipGetErrorString(e));
+        st.pixels = (uint64_t)w * h;
+        for (hipEvent_t ev : done) if (ev) (void)hipEventDestroy(ev);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+      }
+      if (rc) return rc;
+      agg = st;
+      g_last_plan = 3;
+    } else {
+    if (!rc) rc = ensure_frame(0, frame_bytes);
     if (!rc && !D.copy_stream) {
       hipError_t e = hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking);
       if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "copy stream: %s", hipGetErrorString(e));
     }
-    const bool count = (flags & RT_FLAG_COUNT) != 0;
-    // counters come from one instrumented launch; a caller that asked for bands (rt_render_progressive) gets that many
-    const uint32_t n_bands = count ? 1u : (want_bands ? want_bands : (frame_bytes < (8u << 20) ? 1u : 4u));
-    const uint32_t band_rows = ((h + n_bands - 1) / n_bands + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+    // The bands (first row, rows).  Counters come from one instrumented launch; a caller that asked for bands (rt_render_progressive)
+    // gets that many.  Frames of 8 MiB and more: 4 bands - measured against 1, 2, 8, 16 equal bands, growing bands and the direct
+    // stores above in profiles/r03_ab_log.md section 4: every plan ends within a few percent of frame bytes / PCIe rate.
+    std::vector<std::pair<uint32_t, uint32_t>> bands;
+    {
+      const uint32_t n = count ? 1u : (want_bands ? want_bands : (frame_bytes < (8u << 20) ? 1u : (uint32_t)g_copy_bands));
+      const uint32_t rows = ((h + n - 1) / n + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+      for (uint32_t r0 = 0; r0 < h; r0 += rows) bands.push_back({r0, rows});
+    }
+    const uint32_t n_bands = (uint32_t)bands.size();
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> band_done(n_bands, nullptr), copy_done(n_bands, nullptr);
     if (!rc) {
@@ -1583,8 +1655,7 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
         if (e == hipSuccess) e = hipEventCreate(&ev1);
         if (e == hipSuccess) e = hipEventRecord(ev0, D.stream);
         for (uint32_t b = 0; b < n_bands && !rc && e == hipSuccess; b++) {
-          const uint32_t r0 = b * band_rows;
-          if (r0 >= h) break;
+          const uint32_t r0 = bands[b].first, band_rows = bands[b].second;
           const uint32_t rows = (r0 + band_rows <= h) ? band_rows : h - r0;
           rt_tiles band = {band_rows, b, 1, 1};
           uint8_t *d_band = (uint8_t *)D.d_frame + (size_t)r0 * w * 4u;
@@ -1603,7 +1674,7 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
         for (uint32_t b = 0; on_band && b < n_bands && e == hipSuccess && !rc; b++) {
           if (!copy_done[b]) break;
           e = hipEventSynchronize(copy_done[b]);
-          const uint32_t r0 = b * band_rows;
+          const uint32_t r0 = bands[b].first, band_rows = bands[b].second;
           if (e == hipSuccess) on_band(user, r0, (r0 + band_rows <= h) ? band_rows : h - r0);
         }
         // on EVERY way out the copies already queued into the caller's buffer are finished first: the caller may hand that
@@ -1623,6 +1694,7 @@ int render_to_host(const void *blob, size_t bytes, uint32_t w, uint32_t h, uint8
       agg = st;
     }
     if (rc) return rc;
+    }
   } else {
     // ---- G GPUs of one node (one process): interleaved row tiles (sky rows are cheap, floor rows are not), reassembled
     //      on GPU 0.  Primary plan: PEER STORES - every GPU's kernel writes its tiles straight into GPU 0's frame buffer over

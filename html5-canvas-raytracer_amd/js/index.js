@@ -28,10 +28,14 @@ let inited = false;
 function init(maxDevices) { const n = native().init(maxDevices === undefined ? 1 : maxDevices); inited = true; return n; }
 function flagsOf(opts) { return ((opts && opts.count) ? FLAG_COUNT : 0) | ((opts && opts.strictFp) ? FLAG_STRICT_FP : 0); }
 
-// -> Uint8ClampedArray of length 4*width*height over a pinned host buffer; `.stats` carries timings
+// -> Uint8ClampedArray of length 4*width*height over a pinned host buffer; `.stats` carries timings.
+// opts.into: the frame to fill instead of a new one - the reference creates its ImageData once (main.js:83) and every redraw
+// writes into it again (main.js:195-200).  Hand in what an earlier render() returned (pinned memory: the GPU stores into it
+// directly, nothing is allocated) - or any Uint8ClampedArray of 4*width*height bytes, e.g. a canvas ImageData.data (pageable
+// memory: the frame is copied out of the GPU's memory, about half the rate).  Returns that same array.
 function render(width, height, sceneObj, opts) {
   if (!inited) init(opts && opts.maxDevices);
-  const r = native().render(flattenScene(sceneObj), width, height, flagsOf(opts));
+  const r = native().render(flattenScene(sceneObj), width, height, flagsOf(opts), (opts && opts.into) || undefined);
   r.data.stats = r.stats;
   return r.data;
 }

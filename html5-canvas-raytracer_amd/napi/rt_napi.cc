@@ -87,12 +87,15 @@ bool parse(napi_env env, napi_callback_info info, args *a, bool copy_blob) {
   return true;
 }
 
-napi_value make_result(napi_env env, args *a) {
+// `into`: the caller's own frame (render(..., {into})), handed back as `data`; else a new typed array over the pinned frame
+napi_value make_result(napi_env env, args *a, napi_value into = nullptr) {
   const size_t n = (size_t)a->w * a->h * 4u;
-  napi_value ab, ta, res, stats, v;
-  NAPI_TRY(napi_create_external_arraybuffer(env, a->out, n, free_pinned, nullptr, &ab));
-  a->out = nullptr;    // owned by the ArrayBuffer's finalizer from here on
-  NAPI_TRY(napi_create_typedarray(env, napi_uint8_clamped_array, n, ab, 0, &ta));
+  napi_value ab, ta = into, res, stats, v;
+  if (!into) {
+    NAPI_TRY(napi_create_external_arraybuffer(env, a->out, n, free_pinned, nullptr, &ab));
+    a->out = nullptr;    // owned by the ArrayBuffer's finalizer from here on
+    NAPI_TRY(napi_create_typedarray(env, napi_uint8_clamped_array, n, ab, 0, &ta));
+  }
   NAPI_TRY(napi_create_object(env, &res));
   NAPI_TRY(napi_create_object(env, &stats));
   napi_set_named_property(env, res, "data", ta);
@@ -124,10 +127,35 @@ napi_value Init(napi_env env, napi_callback_info info) {
   return v;
 }
 
+// render(blob, width, height[, flags[, into]]).  `into`: a Uint8ClampedArray / Uint8Array of 4*width*height bytes that receives the
+// frame - the reference creates its ImageData once (main.js:83) and every redraw fills it again (main.js:195-200).  A frame that an
+// earlier render() returned is pinned memory the GPU stores into directly; any other array is pageable memory (slower, same bytes).
 napi_value Render(napi_env env, napi_callback_info info) {
   args a;
   if (!parse(env, info, &a, false)) return nullptr;
   napi_value res = nullptr;
+  {
+    size_t argc = 5;
+    napi_value argv[5];
+    napi_valuetype t = napi_undefined;
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc >= 5) napi_typeof(env, argv[4], &t);
+    if (argc >= 5 && t != napi_undefined && t != napi_null) {
+      bool is_ta = false;
+      napi_is_typedarray(env, argv[4], &is_ta);
+      napi_typedarray_type tt = napi_int8_array; size_t len = 0, off = 0; void *data = nullptr; napi_value ab;
+      if (is_ta) napi_get_typedarray_info(env, argv[4], &tt, &len, &data, &ab, &off);
+      if (!is_ta || (tt != napi_uint8_array && tt != napi_uint8_clamped_array) || len != (size_t)a.w * a.h * 4u || !data) {
+        if (a.owned) free(a.blob);
+        napi_throw_type_error(env, nullptr, "into must be a Uint8ClampedArray / Uint8Array of 4*width*height bytes");
+        return nullptr;
+      }
+      a.rc = rt_render(a.blob, a.bytes, a.w, a.h, (uint8_t *)data, a.flags, &a.st);
+      res = (a.rc != RT_OK) ? throw_rt(env, "rt_render", a.rc) : make_result(env, &a, argv[4]);
+      if (a.owned) free(a.blob);
+      return res;
+    }
+  }
   a.out = (uint8_t *)rt_alloc_pinned((size_t)a.w * a.h * 4u);
   if (!a.out) res = throw_rt(env, "rt_alloc_pinned", RT_ERR_NOMEM);
   else {

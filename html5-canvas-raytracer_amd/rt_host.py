@@ -162,6 +162,7 @@ ABI = {
     "rt_render": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(RtStats)]),
     "rt_render_progressive": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.POINTER(RtStats)]),
+    "rt_render_options": (C.c_int, [C.c_int, C.c_uint32]),
     "rt_alloc_pinned": (C.c_void_p, [C.c_size_t]),
     "rt_free_pinned": (None, [C.c_void_p]),
     "rt_alloc_device": (C.c_void_p, [C.c_int, C.c_size_t]),

@@ -237,12 +237,19 @@ int rt_ipc_export(int device, const void *d_ptr, void *handle_out);
 int rt_ipc_open(int device, const void *handle, void **d_ptr_out);
 int rt_ipc_close(int device, void *d_ptr);
 
-/* render(width,height,scene): whole frame into HOST memory (any host pointer; memory from
- * rt_alloc_pinned makes the copy-out DMA directly).  With more than one GPU in use the
- * frame is sharded by interleaved row tiles and reassembled on GPU 0 with one RCCL gather
- * before the copy-out.  Replaces redraw()/spanish() + ImageData (main.js:83,180-201). */
+/* render(width,height,scene): whole frame into HOST memory (any host pointer; memory from rt_alloc_pinned is what the copy engine
+ * and the GPU's own stores reach directly).  One GPU: frames of 8 MiB and more are rendered as 4 row bands whose copy-out overlaps
+ * the next band's render; into smaller pinned frames the trace kernel stores directly, over PCIe.  Either way the call takes about
+ * max(kernel, frame bytes / PCIe rate).  With more than one GPU in use the frame is sharded by interleaved row tiles and put
+ * together on GPU 0 (peer stores, or one RCCL gather) before the copy-out.  Replaces redraw()/spanish() + ImageData
+ * (main.js:83,180-201). */
 int rt_render(const void *scene_blob, size_t blob_bytes, uint32_t w, uint32_t h,
               uint8_t *out_rgba, uint32_t flags, rt_stats *stats);
+
+/* How the one-GPU rt_render / rt_render_progressive hand the frame over (process-wide; for measurements - the defaults (1, 4) follow
+ * profiles/r03_ab_log.md section 4).  direct_stores: 0 never, 1 the kernel stores straight into a pinned caller buffer for frames
+ * below 8 MiB, 2 for every pinned caller buffer.  copy_bands (1..64): the bands of the copy-out plan for frames of 8 MiB and more. */
+int rt_render_options(int direct_stores, uint32_t copy_bands);
 
 /* The same, delivered progressively: the frame is rendered as n_bands (1..64) row bands and on_band(user, first_row,
  * n_rows) is called - on the calling thread, in row order - as soon as a band's rows are in out_rgba, while later bands

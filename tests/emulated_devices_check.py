@@ -6,7 +6,7 @@ written straight into device 0's frame (peer-store plan), or - with RT_FORCE_GAT
 (device-to-device copies when emulated, ncclGather otherwise: with ONE real device that is a one-rank RCCL communicator,
 the real symbols on a one-GPU box) and de-interleaved.  Every case is rendered TWICE, the second time twice as high, so
 the per-device buffers grow between calls.  Prints one line per render:
-    RESULT <scene> <w> <h> <devices> <plan: 0 one GPU, 1 peer stores, 2 gather> <sha256 of the RGBA8 frame>
+    RESULT <scene> <w> <h> <devices> <plan: 0 one GPU with a copy-out, 1 peer stores, 2 gather, 3 one GPU storing into the pinned frame> <sha256 of the RGBA8 frame>
 """
 import hashlib
 import os

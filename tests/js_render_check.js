@@ -27,6 +27,18 @@ function maxDiff(a, b) { let m = 0; if (a.length !== b.length) return 999; for (
   out.constructed = maxDiff(rt.render(h8.w, h8.h, rt.scenes.h8(tex, 3)), fs.readFileSync(path.join(GOLD, h8.file)));
   const a = await rt.renderAsync(h8.w, h8.h, load('h8'));
   out.async = maxDiff(a, fs.readFileSync(path.join(GOLD, h8.file)));
+  // {into}: the reference's ImageData is created once and filled by every redraw (main.js:83, 195-200)
+  {
+    const gold = fs.readFileSync(path.join(GOLD, h8.file));
+    const again = rt.render(h8.w, h8.h, load('cfg2'), {into: a});                   // a pinned frame from an earlier render, another scene first
+    const back = rt.render(h8.w, h8.h, load('h8'), {into: a});
+    const plain = new Uint8ClampedArray(h8.w * h8.h * 4);                           // pageable memory (what a canvas ImageData.data is)
+    const p = rt.render(h8.w, h8.h, load('h8'), {into: plain});
+    let threw = null;
+    try { rt.render(h8.w, h8.h, load('h8'), {into: new Uint8ClampedArray(16)}); } catch (e) { threw = String(e.message || e); }
+    out.into = {sameObject: again === a && back === a && p === plain, pinned: maxDiff(back, gold), pageable: maxDiff(plain, gold), wrongSize: threw,
+      stats: typeof back.stats.total_ms};
+  }
   // progressive delivery: bands arrive in row order, each band's view holds the reference's rows at the moment it is
   // announced, the bands cover the frame exactly, and the resolved frame is the whole frame
   {

@@ -603,7 +603,8 @@ def test_rt_render_multi_device_plans(lib, devices, gather):
             k += 1
             assert got[:4] == [scene, str(w), str(hh), str(devices)]
             sharded = hh >= devices * 8
-            assert int(got[4]) == ((2 if gather else 1) if (sharded and (devices > 1 or gather)) else 0), (scene, w, hh, got)
+            # (3: one GPU storing straight into the pinned frame rt_host.render hands in - frames below 8 MiB)
+            assert int(got[4]) == ((2 if gather else 1) if (sharded and (devices > 1 or gather)) else (3 if w * hh * 4 < (8 << 20) else 0)), (scene, w, hh, got)
             want = hashlib.sha256(gpu_frame(lib, rt_host.flatten_scene(rt_host.load_scene(scene)), w, hh)).hexdigest()
             assert got[5] == want, (scene, w, hh, devices, gather)
 
@@ -1284,3 +1285,35 @@ def test_the_owner_fills_the_sky_and_the_senders_leave_it_out(lib, scene, w, h, 
     finally:
         r.close()
         lib.rt_free_device(0, d)
+
+
+def test_rt_render_hands_the_frame_over_the_same_bytes_every_way(lib):
+    """rt_render on one GPU: the kernel storing straight into a pinned frame (the default for rt_alloc_pinned memory, what the N-API
+    layer hands in), the banded copy-out (1, 4, 5, 8 bands) and a pageable destination give the same bytes; so do the bands of
+    rt_render_progressive, announced in order, under both plans.  Odd sizes: the last band is ragged."""
+    for scene, w, h in (("h8", 1920, 1200), ("default14", 2051, 1031), ("lcg64_ss3", 1536, 1400)):
+        blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+        buf = C.create_string_buffer(blob, len(blob))
+        n = w * h * 4
+        assert n >= 8 << 20                                       # (smaller frames take one band whatever the option says)
+        want = gpu_frame(lib, blob, w, h, FAST)
+        pinned = lib.rt_alloc_pinned(n)
+        pageable = C.create_string_buffer(n)
+        try:
+            for direct, bands, dst in ((2, 4, pinned), (1, 4, pinned), (0, 1, pinned), (0, 5, pinned), (0, 8, pinned), (2, 4, C.addressof(pageable))):
+                assert lib.rt_render_options(direct, bands) == 0
+                C.memset(dst, 0, n)
+                st = rt_host.RtStats()
+                assert lib.rt_render(buf, len(blob), w, h, C.c_void_p(dst), 0, C.byref(st)) == 0, lib.rt_last_error()
+                assert C.string_at(dst, n) == want, (scene, direct, bands)
+                assert st.pixels == w * h and st.kernel_ms > 0 and st.total_ms >= st.kernel_ms * 0.5
+                seen = []
+                cb = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)(lambda user, r0, rows: seen.append((r0, rows)))
+                C.memset(dst, 0, n)
+                assert lib.rt_render_progressive(buf, len(blob), w, h, C.c_void_p(dst), 7, cb, None, 0, C.byref(st)) == 0, lib.rt_last_error()
+                assert C.string_at(dst, n) == want, (scene, direct, bands, "progressive")
+                assert [r for r, _ in seen] == [sum(k for _, k in seen[:i]) for i in range(len(seen))] and sum(k for _, k in seen) == h and 1 < len(seen) <= 7
+        finally:
+            lib.rt_render_options(1, 4)
+            lib.rt_free_pinned(pinned)
+    assert lib.rt_render_options(1, 65) != 0 and lib.rt_render_options(1, 0) != 0 and lib.rt_render_options(3, 4) != 0
