@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity debugging aid (run by hand on the GPU box; NOT collected by pytest):
 
-    RT_HIP_LIB=html5-canvas-raytracer_amd/csrc/librt_hip_test.so python tests/debug_flips.py 1153727 1189883 d1101 m5000 ...
+    RT_HIP_LIB=html5-canvas-raytracer_amd/csrc/librt_hip_test.so python tests/debug/flips.py 1153727 1189883 d1101 m5000 ...
 
 For each soak seed (prefix d = drawn with --degenerate-lights, m = --many-spheres) it renders the scene with both kernels
 and the C restatement, lists the pixels that differ by more than 1 LSB, and for each of them (up to --max) prints the
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "html5-canvas-raytracer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_util as ou  # noqa: E402

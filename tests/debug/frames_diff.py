@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Hand-run GPU debugging aid: where do two renders of a scene differ?   python tests/debug_ss.py"""
+"""Hand-run GPU debugging aid: where do two renders of a scene differ?   python tests/debug/frames_diff.py"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "html5-canvas-raytracer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_util as ou  # noqa: E402
