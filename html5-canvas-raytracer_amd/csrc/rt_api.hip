@@ -793,7 +793,7 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
   hipError_t er = (hipError_t)rt_launch_small_copy((void *)e.T.params, st, copy_bytes, cam ? s->d_cam : nullptr, cam ? cam->h : nullptr, cam ? s->cam_bytes_used : 0u, stream);
   if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
   if (er == hipSuccess && cam) er = camera_copied(s, cam, stream);
-  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, stream);
+  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, (P.flags & RT_TABLE_WIDE) ? 1 : 0, stream);
   if (er == hipSuccess) er = hipEventRecord(e.built, stream);
   if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return -1; }
   return found;

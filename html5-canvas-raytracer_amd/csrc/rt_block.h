@@ -93,10 +93,17 @@ RT_HD inline uint32_t rt_block_cost(const rt_table_params &P, const rt_cost_rect
   return cost < RT_COST_MAX ? cost : RT_COST_MAX;
 }
 
-// touched / candidates / shadow masks of block (x, y); *touched = 1 also when nothing can be said
-RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *balls, uint32_t x, uint32_t y, uint32_t *touched, uint32_t *cands_out, uint32_t *smask_out) {
-  *touched = 1u; *cands_out = 0u; *smask_out = 0xffffffffu;
-  if (!(P.flags & RT_TABLE_GEOMETRY)) return;
+// The statement of block (x, y) in pieces, so that the host (one block after the other, rt_block_statement below) and the device
+// (rt_tables_gpu.hip: eight work-items per block, one sphere each) run the SAME operations on the same values and state the same words.
+
+// the cone of the block's primary rays: unit axis, cos / sin of the half-angle; hit: the block counts as touched whatever the spheres
+// say; doubt: nothing can be said about it (no geometry, or a box wider than a half space: never at these fields of view)
+struct rt_cone { double ax[3], cos_a, sin_a; uint32_t hit, doubt; };
+
+RT_HD inline rt_cone rt_block_cone(const rt_table_params &P, uint32_t x, uint32_t y) {
+  rt_cone K;
+  K.ax[0] = K.ax[1] = K.ax[2] = 0.0; K.cos_a = 1.0; K.sin_a = 0.0; K.hit = 1u; K.doubt = 1u;
+  if (!(P.flags & RT_TABLE_GEOMETRY)) return K;
   const double row0 = rt_block_row0(P, y);
   const double Y1 = (P.proj_h - 0.5) - row0, Y0 = Y1 - (double)(P.wg_h - 1u);
   const double X0 = (double)((uint64_t)x * P.wg_w) + (0.5 - P.proj_w), X1 = X0 + (double)(P.wg_w - 1u);
@@ -108,71 +115,105 @@ RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *ba
     for (int c = 0; c < 3; c++) ax[c] += u[k][c];
   }
   const double al = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-  bool hit = !(al > 1e-3), doubt = hit;              // (a box wider than a half space: never at these fields of view)
+  bool hit = !(al > 1e-3);                           // (a box wider than a half space)
   double cos_a = 1.0;
   if (!hit) {
     const double ial = 1.0 / al;
     for (int c = 0; c < 3; c++) ax[c] *= ial;
     for (int k = 0; k < 4; k++) cos_a = fmin(cos_a, ax[0] * u[k][0] + ax[1] * u[k][1] + ax[2] * u[k][2]);
     cos_a = fmax(cos_a - 1e-9, 0.0);                 // a slightly wider cone
-    hit = doubt = !(cos_a > 1e-3);
+    hit = !(cos_a > 1e-3);
   }
-  const double sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
+  K.ax[0] = ax[0]; K.ax[1] = ax[1]; K.ax[2] = ax[2];
+  K.cos_a = cos_a; K.sin_a = sqrt(fmax(0.0, 1.0 - cos_a * cos_a));
+  K.hit = K.doubt = hit ? 1u : 0u;
+  return K;
+}
+
+// can some ray of the cone meet sphere B?  0: no; 1: yes (or NaN: touched); 2: the camera is inside / on / too near B - no statement
+// about any block
+RT_HD inline uint32_t rt_ball_touch(const rt_cone &K, const rt_ball &B) {
+  if (B.everywhere) return 2u;
+  const double cos_ab = K.cos_a * B.cos_b - K.sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
+  const double cs = K.ax[0] * B.c[0] + K.ax[1] * B.c[1] + K.ax[2] * B.c[2];
+  return (cs < cos_ab - 1e-7) ? 0u : 1u;             // untouched iff angle(axis, C) > alpha + beta, with a margin
+}
+
+// word 3 from the set of candidates (a bit per ball, at most 256; n_cand of them): count << 16 | loop index of the second << 8 |
+// loop index of the first (in index order: the tie-break of the search), or 0
+RT_HD inline uint32_t rt_cand_word(const rt_table_params &P, const rt_ball *balls, const uint64_t cand[4], uint32_t n_cand) {
+  if (!(P.flags & RT_TABLE_CANDS) || n_cand == 0u || n_cand > 2u) return 0u;
+  uint32_t idx[2] = {0u, 0u}, got = 0;
+  for (uint32_t j = 0; j < P.n_balls && got < n_cand; j++) if (cand[j >> 6] >> (j & 63u) & 1ull) idx[got++] = balls[j].loop;
+  uint32_t i0 = idx[0], i1 = n_cand > 1u ? idx[1] : 0u;
+  if (n_cand > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
+  return (n_cand << 16) | (i1 << 8) | i0;
+}
+
+// candidate sphere ci: which spheres can stand between the block's primary hits on it and light k - OR-ed into mk[k].  false: no
+// statement can be made (the block's word is then 0xffffffff whatever the other candidates say)
+RT_HD inline bool rt_cand_masks(const rt_table_params &P, const rt_cone &K, const rt_ball *balls, uint32_t ci, uint32_t mk[2]) {
+  const rt_ball &B = balls[ci];
+  const double *ax = K.ax;
+  const double cos_a = K.cos_a, sin_a = K.sin_a;
+  // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
+  const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
+  const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
+  const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), B.tangent);
+  // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
+  // to a sphere gets no statement)
+  if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(P.epsilon))) return false;
+  const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
+  if (!(t2 >= t1) || !(t1 >= 0.0) || !(t2 <= 1.7976931348623157e308)) return false;
+  const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
+  const double Q[3] = {P.cam[0] + m * ax[0], P.cam[1] + m * ax[1], P.cam[2] + m * ax[2]};
+  const bool wide = (P.flags & RT_TABLE_WIDE) != 0u;
+  for (uint32_t k = 0; k < P.n_lights; k++) {
+    if (wide && mk[k] == 0xffffu) continue;        // many spheres: a light's set is "empty or not", and it already is not
+    const double V[3] = {Q[0] - P.lights[k][0], Q[1] - P.lights[k][1], Q[2] - P.lights[k][2]};
+    const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+    // the patch seen from the light: a cone of half-angle asin(rho / dist) around V (the light inside the patch: every sphere)
+    const bool patch_ok = (dist > rho * (1.0 + 1e-7)) && (dist <= 1.7976931348623157e308);
+    const double s1 = patch_ok ? rho / dist : 0.0, c1 = sqrt(1.0 - s1 * s1), reach = (dist + rho) * (1.0 + 1e-7);
+    for (uint32_t j = 0; j < P.n_balls; j++) {
+      if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
+      const rt_ball &O = balls[j];
+      bool inc = true;                             // light inside the occluder or the patch
+      if (patch_ok && !O.always[k]) {
+        // angle(V, W) <= asin(rho / dist) + asin(R / wl), as cosines scaled by |V| |W| (no division per sphere), and the occluder's
+        // nearest point not beyond the patch
+        const double cos12 = c1 * O.c2[k] - s1 * O.s2[k], vw = V[0] * O.lw[k][0] + V[1] * O.lw[k][1] + V[2] * O.lw[k][2];
+        inc = !(vw < (cos12 - 1e-7) * (dist * O.wl[k])) && (O.wl_minus_R[k] <= reach);
+      }
+      if (inc) { if (wide) { mk[k] = 0xffffu; break; } mk[k] |= 1u << O.loop; }
+    }
+  }
+  return true;
+}
+
+// touched / candidates / shadow masks of block (x, y), one block after the other (the host); *touched = 1 also when nothing can be said
+RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *balls, uint32_t x, uint32_t y, uint32_t *touched, uint32_t *cands_out, uint32_t *smask_out) {
+  *touched = 1u; *cands_out = 0u; *smask_out = 0xffffffffu;
+  const rt_cone K = rt_block_cone(P, x, y);
+  bool hit = K.hit != 0u, doubt = K.doubt != 0u;
+  if (!(P.flags & RT_TABLE_GEOMETRY)) return;
   // which spheres the cone can meet: a bit per ball (at most 256)
   uint64_t cand[4] = {0ull, 0ull, 0ull, 0ull};
   uint32_t n_cand = 0;
   for (uint32_t j = 0; j < P.n_balls && !doubt; j++) {
-    const rt_ball &B = balls[j];
-    if (B.everywhere) { hit = doubt = true; break; }
-    const double cos_ab = cos_a * B.cos_b - sin_a * B.sin_b;          // cos(alpha + beta); alpha + beta < pi here
-    const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2];
-    if (!(cs < cos_ab - 1e-7)) { hit = true; cand[j >> 6] |= 1ull << (j & 63u); n_cand++; }   // untouched iff angle(axis, C) > alpha + beta, with a margin (NaN: touched)
+    const uint32_t t = rt_ball_touch(K, balls[j]);
+    if (t == 2u) { hit = doubt = true; break; }
+    if (t) { hit = true; cand[j >> 6] |= 1ull << (j & 63u); n_cand++; }
   }
   *touched = hit ? 1u : 0u;
   if (doubt || n_cand == 0u) return;
-  // word 3: count << 16 | loop index of the second << 8 | loop index of the first (in index order: the tie-break of the search)
-  if ((P.flags & RT_TABLE_CANDS) && n_cand <= 2u) {
-    uint32_t idx[2] = {0u, 0u}, got = 0;
-    for (uint32_t j = 0; j < P.n_balls && got < n_cand; j++) if (cand[j >> 6] >> (j & 63u) & 1ull) idx[got++] = balls[j].loop;
-    uint32_t i0 = idx[0], i1 = n_cand > 1u ? idx[1] : 0u;
-    if (n_cand > 1u && i1 < i0) { const uint32_t t = i0; i0 = i1; i1 = t; }
-    *cands_out = (n_cand << 16) | (i1 << 8) | i0;
-  }
+  *cands_out = rt_cand_word(P, balls, cand, n_cand);
   if (!(P.flags & RT_TABLE_MASKS)) return;
   uint32_t mk[2] = {0u, 0u};
   for (uint32_t ci = 0; ci < P.n_balls; ci++) {
     if (!(cand[ci >> 6] >> (ci & 63u) & 1ull)) continue;
-    const rt_ball &B = balls[ci];
-    // the primary hits on sphere ci: distances [t1, t2] along rays within alpha of the axis
-    const double cs = fmin(1.0, fmax(-1.0, ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2])), sn = sqrt(1.0 - cs * cs);
-    const double c_hi = B.len * ((cs * cos_a + sn * sin_a >= 1.0 || sn <= sin_a) ? 1.0 : cs * cos_a + sn * sin_a);
-    const double c_lo = fmax(B.len * (cs * cos_a - sn * sin_a), B.tangent);
-    // (the kernel takes the FAR root when the near one lies within epsilon of the origin, main.js:431-436: a camera that close
-    // to a sphere gets no statement)
-    if (!(B.k > 0.0) || !(c_hi * c_hi >= B.k) || !(c_hi >= c_lo) || !(B.len - B.R >= 2.0 * fabs(P.epsilon))) return;
-    const double t1 = (c_hi - sqrt(fmax(c_hi * c_hi - B.k, 0.0))) * (1.0 - 1e-6), t2 = (c_lo - sqrt(fmax(c_lo * c_lo - B.k, 0.0))) * (1.0 + 1e-6);
-    if (!(t2 >= t1) || !(t1 >= 0.0) || !(t2 <= 1.7976931348623157e308)) return;
-    const double m = 0.5 * (t1 + t2), rho = sqrt(0.25 * (t2 - t1) * (t2 - t1) + 2.0 * t2 * m * (1.0 - cos_a)) * (1.0 + 1e-6) + 1e-9 * t2;
-    const double Q[3] = {P.cam[0] + m * ax[0], P.cam[1] + m * ax[1], P.cam[2] + m * ax[2]};
-    for (uint32_t k = 0; k < P.n_lights; k++) {
-      const double V[3] = {Q[0] - P.lights[k][0], Q[1] - P.lights[k][1], Q[2] - P.lights[k][2]};
-      const double dist = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-      // the patch seen from the light: a cone of half-angle asin(rho / dist) around V (the light inside the patch: every sphere)
-      const bool patch_ok = (dist > rho * (1.0 + 1e-7)) && (dist <= 1.7976931348623157e308);
-      const double s1 = patch_ok ? rho / dist : 0.0, c1 = sqrt(1.0 - s1 * s1), reach = (dist + rho) * (1.0 + 1e-7);
-      for (uint32_t j = 0; j < P.n_balls; j++) {
-        if (j == ci) continue;                       // a hit on sphere ci skips ci itself (main.js:294)
-        const rt_ball &O = balls[j];
-        bool inc = true;                             // light inside the occluder or the patch
-        if (patch_ok && !O.always[k]) {
-          // angle(V, W) <= asin(rho / dist) + asin(R / wl), as cosines scaled by |V| |W| (no division per sphere), and the occluder's
-          // nearest point not beyond the patch
-          const double cos12 = c1 * O.c2[k] - s1 * O.s2[k], vw = V[0] * O.lw[k][0] + V[1] * O.lw[k][1] + V[2] * O.lw[k][2];
-          inc = !(vw < (cos12 - 1e-7) * (dist * O.wl[k])) && (O.wl_minus_R[k] <= reach);
-        }
-        if (inc) mk[k] |= (P.flags & RT_TABLE_WIDE) ? 0xffffu : (1u << O.loop);
-      }
-    }
+    if (!rt_cand_masks(P, K, balls, ci, mk)) return;
+    if (mk[0] == 0xffffu && mk[1] == 0xffffu) return;       // many spheres, both sets not empty: the word is 0xffffffff whatever follows
   }
   *smask_out = mk[0] | (mk[1] << 16);
 }

@@ -25,7 +25,7 @@ struct rt_table_dev {
 
 #ifdef __HIPCC__
 extern "C" int rt_launch_small_copy(void *dst0, const void *pinned_src0, size_t bytes0, void *dst1, const void *pinned_src1, size_t bytes1, hipStream_t stream);
-extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, hipStream_t stream);   // dyn_bytes: of (params | balls | rects), contiguous from T->params
+extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, int wide, hipStream_t stream);   // dyn_bytes: of (params | balls | rects), contiguous from T->params; wide: RT_TABLE_WIDE (many spheres)
 #endif
 
 #endif

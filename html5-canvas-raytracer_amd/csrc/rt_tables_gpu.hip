@@ -6,8 +6,8 @@
 // what will it cost (rt_block.h) - depends on the camera, the frame size and the tile set; on the host it takes 5-30 ms for a
 // 3840x2160 frame against a 0.07 ms trace.  Here it is three small launches on the render stream, no host step in between:
 //
-//   rt_table_rows   one workgroup per ROW BLOCK (a row of blocks): every work-item states its block (rt_block_statement, rt_block_cost:
-//                   the host's own source), then the row decides in LDS which blocks start an entry - a block that shows a sphere is an
+//   rt_table_rows   one workgroup per ROW BLOCK (a row of blocks): eight work-items state a block (the pieces of rt_block_statement,
+//                   rt_block_cost: the host's own source), then the row decides in LDS which blocks start an entry - a block that shows a sphere is an
 //                   entry of its own, consecutive sky blocks share one (a run never crosses a multiple of 32 blocks, so "do I start a
 //                   run" is a question about the left neighbour) - how many entries of the same cost lie to the left of each (its
 //                   rank among equals in the row), and the row's histogram of entry costs;
@@ -30,7 +30,16 @@
 
 namespace {
 
-constexpr uint32_t WG = 256;
+constexpr uint32_t WG = 256;          // rt_table_emit
+// OR over the SUB adjacent lanes that share a block (a group never straddles a wave; groups are active or idle as a whole)
+template <uint32_t SUB>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+#pragma unroll
+  for (uint32_t d = 1; d < SUB; d <<= 1) v |= (uint32_t)__shfl_xor((int)v, (int)d);
+  return v;
+}
+template <uint32_t SUB>
+__device__ __forceinline__ uint64_t group_or64(uint64_t v) { return (uint64_t)group_or<SUB>((uint32_t)v) | ((uint64_t)group_or<SUB>((uint32_t)(v >> 32)) << 32); }
 
 // The parameters, the cone-test spheres and the cost rectangles are staged in LDS first - one coalesced load per work-item - and
 // read from there: every workgroup is the first on its CU to touch them (a copy kernel wrote them a moment ago), and as scalar
@@ -38,12 +47,21 @@ constexpr uint32_t WG = 256;
 // `stage_bytes` = what of (params | balls | rects), contiguous from T.params on, goes to LDS.  STAGED = false: too many spheres for
 // it - they are read where they are.  (Two instantiations, so that in the staged one every read is known to be an LDS read: through
 // a pointer that may be either, each field is a flat load and its own wait - 20 us of dependent latencies per block.)
-template <bool STAGED>
-__global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32_t stage_bytes) {
+//
+// SUB work-items per block.  With one, a 3840x2160 frame's 32 400 blocks are 506 waves - one per SIMD on half of the chip - and
+// each of them walks, one after the other, every sphere that ANY of its 64 blocks names a candidate (the root interval, the patch,
+// per light a loop over the occluders: ~2800 instructions per wave at ~20 cycles each, a lone wave waiting for its own LDS reads
+// and square roots).  Here work-item `sub` of a block's group takes spheres sub, sub + SUB, ...: the cone (computed by all of
+// them, the same bits), its spheres' cone tests, and for those that are candidates their shadow masks; candidate set, masks and
+// "no statement" are OR-ed across the group (rt_block.h's pieces: the same operations as the host's rt_block_statement, in another
+// order only where the order cannot matter).  Measured (profiles/r03_ab_log.md section 3; 3840x2160): 8 spheres 24.0 us with one
+// work-item per block, 19.6 with four (512-thread workgroups), 27.4 with eight; 64 spheres 817 us with one, 273 with eight.
+template <bool STAGED, uint32_t SUB, uint32_t WG_ROWS>
+__global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, uint32_t stage_bytes) {
   extern __shared__ uint4 lds_raw[];
   if (STAGED) {
     const uint4 *src = (const uint4 *)T.params;
-    for (uint32_t i = threadIdx.x; i < stage_bytes / 16u; i += WG) lds_raw[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < stage_bytes / 16u; i += WG_ROWS) lds_raw[i] = src[i];
     __syncthreads();
   }
   const uint8_t *base = STAGED ? (const uint8_t *)lds_raw : (const uint8_t *)T.params;
@@ -57,14 +75,47 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32
   uint32_t *l_hist = lds + 2u * tiles_x;     // [bins]
   const bool sky = (P.flags & RT_TABLE_SKY) && (P.flags & RT_TABLE_GEOMETRY);
   const bool rank = (P.flags & RT_TABLE_RANK) != 0u;
-  for (uint32_t c = threadIdx.x; c < bins; c += WG) l_hist[c] = 0u;
-  for (uint32_t x = threadIdx.x; x < tiles_x; x += WG) {
-    uint32_t touched, cands, smask;
-#ifdef RT_TAB_NO_STMT   /* timing experiments (profiles/ab_build.sh) */
-    touched = 1u; cands = 0u; smask = 0xffffffffu;
-#else
-    rt_block_statement(P, balls, x, y, &touched, &cands, &smask);
+  for (uint32_t c = threadIdx.x; c < bins; c += WG_ROWS) l_hist[c] = 0u;
+  const uint32_t sub = threadIdx.x % SUB;
+  for (uint32_t x = threadIdx.x / SUB; x < tiles_x; x += WG_ROWS / SUB) {
+    uint32_t touched = 1u, cands = 0u, smask = 0xffffffffu;
+#ifndef RT_TAB_NO_STMT   /* (defined: timing experiments, profiles/ab_build.sh) */
+    if (P.flags & RT_TABLE_GEOMETRY) {
+      const rt_cone K = rt_block_cone(P, x, y);
+      uint64_t cand[4] = {0ull, 0ull, 0ull, 0ull};
+      uint32_t everywhere = 0u;
+      if (!K.doubt)
+        for (uint32_t j = sub; j < P.n_balls; j += SUB) {
+          const uint32_t t = rt_ball_touch(K, balls[j]);
+          if (t == 2u) everywhere = 1u;
+          else if (t) cand[j >> 6] |= 1ull << (j & 63u);
+        }
+      everywhere = group_or<SUB>(everywhere);
+      uint32_t n_cand = 0u;
+#pragma unroll
+      for (uint32_t wd = 0; wd < 4u; wd++) {
+        if (wd * 64u < P.n_balls) cand[wd] = group_or64<SUB>(cand[wd]);      // (uniform: every work-item of the grid sees the same n_balls)
+        n_cand += (uint32_t)__popcll(cand[wd]);
+      }
+      const bool doubt = K.doubt || everywhere;
+      touched = (K.hit || everywhere || n_cand) ? 1u : 0u;
+      if (!doubt && n_cand) {
+        if (sub == 0u) cands = rt_cand_word(P, balls, cand, n_cand);
+        if (P.flags & RT_TABLE_MASKS) {
+          uint32_t mk[2] = {0u, 0u}, none = 0u;
+          for (uint32_t ci = sub; ci < P.n_balls; ci += SUB)
+            if ((cand[ci >> 6] >> (ci & 63u)) & 1ull) {
+              if (!rt_cand_masks(P, K, balls, ci, mk)) none = 1u;
+              if (mk[0] == 0xffffu && mk[1] == 0xffffu) break;       // (as on the host: the word is 0xffffffff whatever follows)
+            }
+          none = group_or<SUB>(none);
+          const uint32_t m0 = group_or<SUB>(mk[0]), m1 = group_or<SUB>(mk[1]);
+          if (!none) smask = m0 | (m1 << 16);
+        }
+      }
+    }
 #endif
+    if (sub != 0u) continue;
 #ifdef RT_TAB_NO_COST
     const uint32_t cost = 1u + (x & 3u);
 #else
@@ -80,7 +131,7 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32
     for (size_t b = (size_t)at + n; b < (size_t)8u * n8; b += n) ((uint4 *)T.entries)[(b & 7u) * n8 + (b >> 3)] = uint4{0u, 0u, 0u, 0u};
   }
   __syncthreads();
-  for (uint32_t x = threadIdx.x; x < tiles_x; x += WG) {
+  for (uint32_t x = threadIdx.x; x < tiles_x; x += WG_ROWS) {
     uint32_t key = 0u, run = 0u;
     if (l_touched[x]) key = 1u + (bins - T.blk[3u * ((size_t)y * tiles_x + x)]);          // dearest first: bin 0 = the largest cost
     else if (x % RT_SKY_RUN_MAX == 0u || l_touched[x - 1u]) {                            // a sky run starts here
@@ -93,7 +144,7 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32
     T.item[(size_t)y * tiles_x + x] = key ? (key | (run << 16)) : 0u;                      // key <= 1024, run <= 32; the rank in the row is added below
   }
   __syncthreads();
-  for (uint32_t x = threadIdx.x; x < tiles_x; x += WG) {
+  for (uint32_t x = threadIdx.x; x < tiles_x; x += WG_ROWS) {
     const uint32_t key = l_key[x];
     if (!key) continue;
     uint32_t before = 0u;                                                                  // entries of the same cost to the left: the grid's order among equals
@@ -102,7 +153,7 @@ __global__ void __launch_bounds__(WG) rt_table_rows(const rt_table_dev T, uint32
 #endif
     T.rank_in_row[(size_t)y * tiles_x + x] = before;
   }
-  for (uint32_t c = threadIdx.x; c < bins; c += WG) T.row_hist[(size_t)y * bins + c] = l_hist[c];
+  for (uint32_t c = threadIdx.x; c < bins; c += WG_ROWS) T.row_hist[(size_t)y * bins + c] = l_hist[c];
 }
 
 // inclusive prefix sum across the 64 lanes of a wave
@@ -194,11 +245,14 @@ extern "C" int rt_launch_small_copy(void *dst0, const void *pinned_src0, size_t 
 }
 
 // Enqueue the three launches on `stream`.  Returns a hipError_t as int.
-extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, hipStream_t stream) {
+extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, int wide, hipStream_t stream) {
   const uint32_t n = tiles_x * ny;
   const uint32_t stage_bytes = dyn_bytes <= 40u * 1024u ? ((dyn_bytes + 15u) & ~15u) : 0u;      // (params | balls | rects) of up to ~170 spheres fit LDS beside the row's arrays
-  if (stage_bytes) hipLaunchKernelGGL(rt_table_rows<true>, dim3(ny), dim3(WG), stage_bytes + (2u * tiles_x + cost_bins) * sizeof(uint32_t), stream, *T, stage_bytes);
-  else hipLaunchKernelGGL(rt_table_rows<false>, dim3(ny), dim3(WG), (2u * tiles_x + cost_bins) * sizeof(uint32_t), stream, *T, 0u);
+  const uint32_t row_bytes = (2u * tiles_x + cost_bins) * sizeof(uint32_t);
+  // few spheres (no more than 16 in the loops: per-sphere shadow sets): four work-items per block; many: eight, in 16-wave workgroups
+  if (!stage_bytes) hipLaunchKernelGGL((rt_table_rows<false, 8u, 1024u>), dim3(ny), dim3(1024), row_bytes, stream, *T, 0u);
+  else if (wide) hipLaunchKernelGGL((rt_table_rows<true, 8u, 1024u>), dim3(ny), dim3(1024), stage_bytes + row_bytes, stream, *T, stage_bytes);
+  else hipLaunchKernelGGL((rt_table_rows<true, 4u, 512u>), dim3(ny), dim3(512), stage_bytes + row_bytes, stream, *T, stage_bytes);
   hipLaunchKernelGGL(rt_table_scan, dim3(cost_bins), dim3(64), 0, stream, *T);
   hipLaunchKernelGGL(rt_table_emit, dim3((n + WG - 1u) / WG), dim3(WG), 0, stream, *T);
   return (int)hipGetLastError();

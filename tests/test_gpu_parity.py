@@ -1176,14 +1176,19 @@ def _host_table(lib, blob, w, h, tiles, ranked):
 @pytest.mark.parametrize("scene,w,h,tiles", [
     ("h8", 3840, 2160, (2160, 0, 1, 1)), ("h8", 3840, 2160, (16, 3, 8, 17)), ("h8", 1001, 333, (16, 1, 3, 7)), ("cfg2", 1920, 1080, (1080, 0, 1, 1)),
     ("default14", 3840, 2160, (2160, 0, 1, 1)), ("default14", 203, 97, (97, 0, 1, 1)), ("lcg64", 4096, 1031, (24, 1, 2, 22)), ("lcg64_ss1", 3840, 2160, (2160, 0, 1, 1)),
-    ("cfg1", 256, 256, (256, 0, 1, 1)), ("cfg1", 1, 1, (1, 0, 1, 1)), ("h8", 65536, 8, (8, 0, 1, 1)), ("soak:31", 3840, 2160, (2160, 0, 1, 1)), ("soak:55", 3840, 2160, (2160, 0, 1, 1))])
+    ("cfg1", 256, 256, (256, 0, 1, 1)), ("cfg1", 1, 1, (1, 0, 1, 1)), ("h8", 65536, 8, (8, 0, 1, 1)), ("soak:31", 3840, 2160, (2160, 0, 1, 1)), ("soak:55", 3840, 2160, (2160, 0, 1, 1)),
+    ("many:3", 1920, 1080, (1080, 0, 1, 1)), ("many:39", 2051, 517, (517, 0, 1, 1)), ("many:1", 640, 360, (8, 2, 3, 11))])     # 200 (read in place, not staged in LDS), 128, 65 spheres
 def test_the_launch_table_built_on_the_gpu_is_the_host_build_word_for_word(lib, scene, w, h, tiles):
-    """The launch table the library renders with is built ON THE GPU (rt_tables_gpu.hip: one work-item per block, rows segmented in
+    """The launch table the library renders with is built ON THE GPU (rt_tables_gpu.hip: eight work-items per block, rows segmented in
     LDS, a stable counting sort by cost) from the same per-block source as the host build (rt_block.h, rt_tables.cpp - the oracle
     of the CPU tests in tests/test_host.py): for every flag combination - ranked or not, sky blocks marked or not, shadow masks and
     candidates or not - the two must agree in the number of entries and in every word of every entry; also after the camera has
     moved (the table is rebuilt in place)."""
-    sc = _soak_scene(int(scene[5:]))[0] if scene.startswith("soak:") else rt_host.load_scene(scene)
+    if scene.startswith("many:"):
+        import soak_gpu_parity as soak
+        sc = soak.draw_scene(int(scene[5:]), False, True)[0]
+    else:
+        sc = _soak_scene(int(scene[5:]))[0] if scene.startswith("soak:") else rt_host.load_scene(scene)
     if sc.get("supersample", 1) > 2:
         sc["supersample"] = 1
     tlib = rt_host.load_library(rt_host.TEST_LIB_PATH)
@@ -1193,7 +1198,7 @@ def test_the_launch_table_built_on_the_gpu_is_the_host_build_word_for_word(lib, 
     try:
         for ranked in range(8):
             assert _gpu_table(tlib, r, w, h, tiles, ranked, sc.get("supersample", 1)) == _host_table(tlib, blob, w, h, tiles, ranked), (scene, ranked)
-        if not scene.startswith("soak:"):
+        if not scene.startswith(("soak:", "many:")):
             cam0 = sc["camera"]["origin"]
             for k in range(3):
                 sc["camera"] = _look_at_camera([cam0[0] + 0.7 * (k + 1), cam0[1] + 0.2 * k, cam0[2] - 0.5 * k], [0.3 * k, 1.0, 0.0])
