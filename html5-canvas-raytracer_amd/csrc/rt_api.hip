@@ -161,7 +161,7 @@ struct rt_scene_dev {
   // behind all of T's arrays; `n_blocks` workgroups are launched until the host has seen the number of entries the build published
   // (`known`: generation << 32 | entries + 1, a pinned host word), from then on exactly that many.
   struct order_entry {
-    uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands;
+    uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t part;
     uint64_t cam_gen; uint32_t n_blocks; size_t hist_words; rt_table_dev T; uint8_t *d_block; volatile unsigned long long *known; hipStream_t built_on; hipEvent_t built;
     bool shared;                   // launched with on a stream other than the one it was built on
   };
@@ -702,12 +702,14 @@ uint32_t known_value(const volatile unsigned long long *p, uint64_t gen) {
 // launches on `stream` (rt_tables_gpu.hip), behind one small copy of its parameters; nothing waits for them.  Called with the
 // scene's launch_mu held.  Returns the entry's index, or -1 (rt_last_error says why).
 int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                   double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, hipStream_t stream) {
+                   double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t sky_part, hipStream_t stream) {
+  // sky_part: 0 every entry; 1 (RT_FLAG_NO_SKY) a table without the sky runs; 2 (RT_FLAG_SKY_ONLY) a table of nothing else - tables of
+  // their own, so that the trace kernel knows nothing of it (a test of the launch record in its prologue cost the headline 1.5 %)
   int found = -1;
   for (size_t i = 0; i < s->orders.size(); i++) {
     const rt_scene_dev::order_entry &e = s->orders[i];
     if (e.w == w && e.h == h && e.ss == ss && e.tile_rows == tiles->tile_rows && e.tile_first == tiles->tile_first && e.tile_stride == tiles->tile_stride &&
-        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates) { found = (int)i; break; }
+        e.n_tiles == tiles->n_tiles && e.ranked == ranked && e.sky == mark_sky && e.masks == shadow_masks && e.cands == name_candidates && e.part == sky_part) { found = (int)i; break; }
   }
   if (found >= 0 && s->orders[found].cam_gen == s->cam_gen) {
     rt_scene_dev::order_entry &e = s->orders[found];
@@ -723,6 +725,7 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
     fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile);
     return -1;
   }
+  P.flags |= sky_part == 1u ? RT_TABLE_NO_SKY : (sky_part == 2u ? RT_TABLE_SKY_ONLY : 0u);
   const uint32_t n = P.tiles_x * P.ny;
   const size_t hist_words = (size_t)P.ny * P.cost_bins;
   if (found < 0) {
@@ -740,7 +743,7 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
     rt_scene_dev::order_entry &e = s->orders[found];
     memset(&e, 0, sizeof e);
     e.w = w; e.h = h; e.ss = ss; e.tile_rows = tiles->tile_rows; e.tile_first = tiles->tile_first; e.tile_stride = tiles->tile_stride; e.n_tiles = tiles->n_tiles;
-    e.ranked = ranked; e.sky = mark_sky; e.masks = shadow_masks; e.cands = name_candidates;
+    e.ranked = ranked; e.sky = mark_sky; e.masks = shadow_masks; e.cands = name_candidates; e.part = sky_part;
     e.known = known_word(s, RT_KNOWN_WORDS + (size_t)found);
     if (e.known) *e.known = 0ull;                        // (a table evicted from this slot may have published its count for the same camera)
   }
@@ -815,7 +818,8 @@ extern "C" int rt_test_launch_table(rt_scene_dev *s, uint32_t w, uint32_t h, con
   const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
   const double pw = (double)w * ss / 2.0, ph = (double)h * ss / 2.0, pd = pw / tan(s->hd.fov_deg * M_PI / 180.0 / 2.0);
   std::lock_guard<std::mutex> lk(s->launch_mu);
-  const int oi = dispatch_order(s, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, (ranked & 4) != 0, (ranked & 4) != 0, stream);
+  const int oi = dispatch_order(s, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, (ranked & 4) != 0, (ranked & 4) != 0,
+                                (ranked & 8) ? 1u : ((ranked & 16) ? 2u : 0u), stream);
   if (oi < 0) return RT_ERR_DEVICE;
   HIP_TRY(hipStreamSynchronize(stream));
   const rt_scene_dev::order_entry &e = s->orders[oi];
@@ -856,7 +860,7 @@ extern "C" int rt_scene_launch_table(const void *blob, size_t bytes, uint32_t w,
   const uint32_t sky_sphere = enclosing_sphere(hd, ob, lights);
   uint32_t n_entries = 0;
   const std::vector<uint32_t> table = build_launch_table(hd, ob, cull, weight, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, sky_sphere,
-                                                         (ranked & 4) != 0, (ranked & 4) != 0, lights, &n_entries);
+                                                         (ranked & 4) != 0, (ranked & 4) != 0, lights, &n_entries, (ranked & 8) ? 1u : ((ranked & 16) ? 2u : 0u));
   if (table.empty()) return fail(RT_ERR_INVALID, "a launch of this size is beyond the launch table");
   *n_workgroups = n_entries;
   if (n_blocks) *n_blocks = tiles_x * tiles->n_tiles * rb_per_tile;
@@ -1110,7 +1114,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   L.n_frames = n_frames;
   L.frame_stride = frame_stride_bytes / 4u;
   L.rgb24 = (flags & RT_FLAG_RGB24) ? 1u : 0u;
-  L.sky_part = (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u);
   L.scatter = d_frames ? 1u : 0u;
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
@@ -1161,7 +1164,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
     const bool name_candidates = !count && !no_shadow_masks;
     const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
-                                  shadow_masks, name_candidates, stream);
+                                  shadow_masks, name_candidates, (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u), stream);
     if (oi < 0) return RT_ERR_DEVICE;
     rt_scene_dev::order_entry &oe = s->orders[oi];
     L.order = oe.T.entries;

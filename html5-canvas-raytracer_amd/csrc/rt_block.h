@@ -39,6 +39,8 @@
 #define RT_TABLE_WIDE 8u         /* more than 16 loop spheres: a light's set is empty (0) or not (0xffff) */
 #define RT_TABLE_RANK 16u        /* list the blocks dearest first */
 #define RT_TABLE_GEOMETRY 32u    /* the camera is usable for the cone test (finite, non-zero axis sums, positive projection distance) */
+#define RT_TABLE_NO_SKY 64u      /* RT_FLAG_NO_SKY: the table holds no entry for sky blocks (their slots stay zero: no workgroup renders them) */
+#define RT_TABLE_SKY_ONLY 128u   /* RT_FLAG_SKY_ONLY: the table holds ONLY the sky runs */
 #define RT_SKY_RUN_MAX 32u       /* consecutive sky blocks of a row block that share ONE entry */
 #define RT_COST_MAX 1023u        /* costs are clamped here (the ranking only has to order the blocks roughly) */
 

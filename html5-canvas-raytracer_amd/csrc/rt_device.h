@@ -79,7 +79,7 @@ struct rt_launch {
   uint32_t enclosing_flat;           // that sphere neither lights nor spawns rays and its colour ignores the hit point: its test is skipped
   uint32_t cull_in_lds;              // 1: few spheres (no shadow grid, no bounce table): the cull rectangles are part of the LDS image, the product launch takes the few-sphere kernel; 0: the many-sphere kernel, every lane fetches its sphere's rectangle from `cull` (HBM / L2)
   uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
-  uint32_t sky_part;                 // 0: every block; 1 (RT_FLAG_NO_SKY): sky blocks are left out; 2 (RT_FLAG_SKY_ONLY): only sky blocks are stored
+  uint32_t reserved_sky;             // (keeps the record's layout)
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
   uint32_t *out_frames[RT_MAX_SCATTER];

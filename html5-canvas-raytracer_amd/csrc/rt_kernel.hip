@@ -787,7 +787,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
 #else
         // (read where it is used, from the kernarg segment: six scalar registers less across the whole loop)
+#ifdef RT_AB_HOT_MISS
+        ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
+#else
         { const rt_launch __attribute__((address_space(4))) *K = rt_cold_args(); ret[0] = K->miss_color[0]; ret[1] = K->miss_color[1]; ret[2] = K->miss_color[2]; }
+#endif
 #endif
 #ifdef RT_TESTING
         if (is_probe && probe_n < RT_PROBE_NODES) {
@@ -887,7 +891,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           // the index comes out of the fixed-point sum (u, v in [0, 1]; widths and heights <= 16384)
           RT_XY_INDEX(xu, xv)
           const uint32_t xi = min(iu, td.width - 1u), yi = min(iv, td.height - 1u);   // memory safety only; u,v <= 1
+#ifdef RT_AB_HOT_TEXEL
+          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+#else
           const uint32_t texel = *(const uint32_t *)(rt_cold_args()->texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
+#endif
           col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
           col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
         } else if (kind == RT_SAMPLER_CHECKER) {
@@ -937,7 +945,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #if RT_STRICT
           double li = L.light_intensity;                               // shared across lights (q2)
 #else
+#ifdef RT_AB_HOT_LI
+          double li = L.light_intensity;
+#else
           double li = rt_cold_args()->light_intensity;                 // shared across lights (q2); read where it is used (two scalar registers less across the loop)
+#endif
 #endif
 #if !RT_STRICT
           [[maybe_unused]] uint32_t smask = ~0u;
@@ -1402,10 +1414,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
   // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last
   // entry are zero (rt_tables_gpu.hip)
+#ifndef RT_AB_NO_ZERO_EXIT   /* (defined: timing experiment) */
   if (P0.rows_valid == 0u) return;
-  // RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY (a frame assembled from several GPUs' tiles: the OWNER fills the sky blocks of the whole frame from
-  // its own table, the others do not send them over the links): this workgroup's kind of block is not this launch's
-  if (L.sky_part != 0u && ((L.sky_part == 1u) == P0.sky)) return;
+#endif
+  // (RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY - a frame assembled from several GPUs' tiles: the OWNER fills the sky blocks of the whole frame,
+  // the others do not send them over the links - are launch tables of their own, without the entries the launch leaves out: this
+  // kernel knows nothing of it.  As a test of the launch record here it cost the headline 1.5 %.)
 #endif
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};

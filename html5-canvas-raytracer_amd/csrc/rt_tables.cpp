@@ -332,7 +332,7 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
                                          const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries) {
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries, uint32_t sky_part) {
   if (n_entries) *n_entries = 0;
   rt_table_params P;
   std::vector<rt_ball> balls;
@@ -385,6 +385,7 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
     uint32_t w0, w1;
     rt_block_place(P, it.x, it.y, &w0, &w1);
     const uint32_t b = rank ? start[cmax - it.cost]++ : next++;                               // the workgroup that renders this entry
+    if (it.run ? sky_part == 1u : sky_part == 2u) continue;                                    // RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY: the slot stays zero
     const size_t at = (size_t)(b & 7u) * n8 + (b >> 3);
     const size_t blk = (size_t)it.y * tiles_x + it.x;
     table[RT_ENTRY_WORDS * at] = w0;

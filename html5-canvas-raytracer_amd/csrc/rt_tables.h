@@ -37,7 +37,7 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
                                          const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
-                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries);
+                                         bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries, uint32_t sky_part = 0u);
 // the parameters, cone-test spheres and cost rectangles of a launch table (rt_block.h), shared by the host build and the GPU build;
 // returns non-zero when the launch is beyond the table
 int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,

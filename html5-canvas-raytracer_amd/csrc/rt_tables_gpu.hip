@@ -217,6 +217,9 @@ __global__ void __launch_bounds__(WG) rt_table_emit(const rt_table_dev T) {
   if (!it) return;
   const uint32_t y = at / P.tiles_x, x = at - y * P.tiles_x;
   const uint32_t bin = (it & 0xffffu) - 1u, run = it >> 16;
+  // a frame put together from several GPUs' tiles: the senders' tables hold no sky entries, the owner's fill table nothing else
+  // (ranks and counts are those of the whole table; a slot without an entry stays zero and its workgroup leaves at once)
+  if (run ? (P.flags & RT_TABLE_NO_SKY) : (P.flags & RT_TABLE_SKY_ONLY)) return;
   const uint32_t b = T.bin_start[bin] + T.row_hist[(size_t)y * P.cost_bins + bin] + T.rank_in_row[at];     // the workgroup that renders this entry
   const uint32_t n8 = (n + 7u) / 8u;                  // the table's stride: from the number of BLOCKS (known to the host before the build)
   uint32_t w0, w1;

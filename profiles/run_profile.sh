@@ -14,7 +14,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 SUM=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-pmc $*"   # the default command (2000 steps, 20 warm-up), minus the CPU leg and bench.py's own counter passes
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-pmc --no-cold $*"   # the default command (2000 steps, 20 warm-up), minus the CPU leg, bench.py's own counter passes and the cold-frame / moving-camera legs (their rt_trace launches - one workgroup per block - would mix into the averages of the timed ones)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?" >> "$OUT/trace.log"

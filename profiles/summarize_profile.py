@@ -24,6 +24,17 @@ durs = defaultdict(list)
 for f in find("trace/**/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
+# the same kernel launched with different grids is listed per grid (bench.py's default command renders the timed frames with one
+# workgroup per launch-table ENTRY, the frames behind a camera move with one per BLOCK: the count is still on the device there)
+by_grid = defaultdict(list)
+for k, v in durs.items():
+    for d, r in v:
+        by_grid[(k, r.get("Grid_Size_X", r.get("Grid_Size")))].append(d)
+lines.append("")
+lines.append("== rt_trace launches by grid size ==")
+for (k, g), d in sorted(by_grid.items(), key=lambda kv: -sum(kv[1])):
+    if "rt_trace" in k:
+        lines.append("%-80s grid=%s calls=%d avg=%.2f us min=%.1f us max=%.1f us" % (k[:80], g, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
 lines.append("")
 lines.append("== per-kernel durations from the kernel trace ==")
 kern = {}
@@ -33,7 +44,7 @@ for k, v in sorted(durs.items(), key=lambda kv: -sum(d for d, _ in kv[1])):
     kern[k] = {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
     lines.append("%-90s calls=%d avg=%.1f us min=%.1f us max=%.1f us  VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s" % (
         k[:90], len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
-        r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+        r.get("Scratch_Size"), r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Workgroup_Size")))
 
 # ---- counters: average per dispatch of the trace kernel
 pmc = defaultdict(lambda: defaultdict(list))

@@ -1196,7 +1196,7 @@ def test_the_launch_table_built_on_the_gpu_is_the_host_build_word_for_word(lib, 
     blob = rt_host.flatten_scene(sc)
     r = rt_host.Renderer(blob, 0, tlib)
     try:
-        for ranked in range(8):
+        for ranked in list(range(8)) + [7 | 8, 7 | 16, 3 | 8, 6 | 16, 5 | 16]:      # (| 8: RT_FLAG_NO_SKY's table, without the sky runs; | 16: RT_FLAG_SKY_ONLY's, nothing else)
             assert _gpu_table(tlib, r, w, h, tiles, ranked, sc.get("supersample", 1)) == _host_table(tlib, blob, w, h, tiles, ranked), (scene, ranked)
         if not scene.startswith(("soak:", "many:")):
             cam0 = sc["camera"]["origin"]
