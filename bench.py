@@ -25,10 +25,10 @@ across the N ranks.  Two plans put a frame together on the rank that owns it:
     frame buffer - peer-mapped once through IPC handles - rows in frame order, RGBA8, whole 128-byte lines.  No data
     collective, no send/recv buffers, no de-interleave: one all_reduce of one int per group of steps is the barrier.
     Set-up and a one-step PRE-FLIGHT (every owner checks its frame against the reference's rows) run first; any failure on
-    any rank makes all ranks fall back to the exchange plan, and the JSON says so.  Default from N=6 in batch mode and at
-    any N>1 in single-frame mode; then BOTH plans are timed for a few groups of steps and the faster one (slowest rank
-    decides) runs the measurement (`config.plan_calibration_ms_per_step`).  RT_BENCH_P2P=1/0 forces a plan, =auto
-    calibrates at any N.
+    any rank makes all ranks fall back to the exchange plan, and the JSON says so.  Senders leave the constant-background
+    blocks out (RT_FLAG_NO_SKY) and each owner stores them itself (RT_FLAG_SKY_ONLY): half of the headline's pixels never
+    cross a link.  Default at every N>1: BOTH plans are set up and timed for a few groups of steps and the faster one (slowest
+    rank decides) runs the measurement (`config.plan_calibration_ms_per_step`).  RT_BENCH_P2P=1/0 forces a plan.
 
 The scene is resident in HBM before the timed region and the frames stay in HBM (PCIe copy-out rate: DESIGN.md §6, never here).
 
@@ -346,7 +346,8 @@ def main():
             p2p_env = None
             p2p = multi
         else:
-            p2p = multi and (p2p_env == "1" or (p2p_env is None and (world >= 6 or (single and world > 1))))
+            # (default since round 3: both plans at every N > 1, the faster one measured - the peer stores carry half the bytes now)
+            p2p = multi and (p2p_env == "1" or p2p_env is None)
         a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
         plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
         batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
