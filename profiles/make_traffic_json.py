@@ -5,8 +5,8 @@ import json
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = {"h8_3840x2160": "r02_rocprof_summary.json", "default14_3840x2160": "r02_default14_rocprof_summary.json",
-           "lcg64_3840x2160": "r02_lcg64_rocprof_summary.json"}
+SOURCES = {"h8_3840x2160": "r03_rocprof_summary.json", "default14_3840x2160": "r03_default14_rocprof_summary.json",
+           "lcg64_3840x2160": "r03_lcg64_rocprof_summary.json"}
 out = {}
 for key, name in SOURCES.items():
     path = os.path.join(HERE, name)
