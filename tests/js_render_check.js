@@ -62,5 +62,15 @@ function maxDiff(a, b) { let m = 0; if (a.length !== b.length) return 999; for (
   try { const s = load('cfg1'); s.objects[0].mtl.sampler = {kind: 9}; rt.render(8, 8, s); } catch (e) { threw = e.message; }
   out.unsupported = threw;
   rt.shutdown();
+  // an animation: lookAt per frame (main.js:92-100; every redraw() recomputes everything, main.js:180-201).  The resident scene only
+  // moves its camera (rt_scene_set_camera inside rt_render); each frame must be what a library that has never seen the scene renders
+  {
+    const sc = load('h8'), w = 320, hgt = 180, cams = [[1.5, 2.0, 9.0], [-2.0, 1.0, 8.0], [0.5, 3.0, 11.0]];
+    const moved = cams.map((o) => { sc.camera = rt.lookAt(o, [0, 1, 0], [0, 1, 0]); return Buffer.from(rt.render(w, hgt, sc)); });
+    rt.shutdown(); rt.init(1);
+    const fresh = cams.map((o) => { const s2 = load('h8'); s2.camera = rt.lookAt(o, [0, 1, 0], [0, 1, 0]); rt.shutdown(); rt.init(1); return Buffer.from(rt.render(w, hgt, s2)); });
+    out.animation = {frames: cams.length, same: moved.every((m, i) => Buffer.compare(m, fresh[i]) === 0), distinct: Buffer.compare(moved[0], moved[1]) !== 0};
+  }
+  rt.shutdown();
   console.log(JSON.stringify(out));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -153,10 +153,10 @@ def main():
             w, h = wrng.choice([(3840, 2160), (3840, 2160), (7680, 4320)])
             scene["supersample"] = 1
             n_t = h // 8
-            t0 = wrng.randrange(0, n_t - 1)
-            stride = wrng.randrange(1, n_t - t0)
-            tiles = rt_host.RtTiles(8, t0, stride, 2)
-            rows = [8 * t + k for t in (t0, t0 + stride) for k in range(8)]
+            tile0 = wrng.randrange(0, n_t - 1)
+            stride = wrng.randrange(1, n_t - tile0)
+            tiles = rt_host.RtTiles(8, tile0, stride, 2)
+            rows = [8 * t + k for t in (tile0, tile0 + stride) for k in range(8)]
         blob = rt_host.flatten_scene(scene)
         n_px = (len(rows) if rows else h) * w
         want = np.frombuffer(ou.c_oracle_rows(blob, w, h, rows) if rows else ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(n_px, 4).astype(np.int16)

@@ -578,7 +578,7 @@ def test_rt_render_multi_device_plans(lib, devices, gather):
         ranks on one GPU); with devices == 1 it is the REAL RCCL path - ncclCommInitAll, ncclGroupStart/End and ncclGather
         on a one-rank communicator.
     Cases: 16-row tiles + RGB24 bands (headline size), 8-row tiles, a width that forces RGBA8 bands, odd sizes (centre row /
-    column fix-up launches inside the tiles), the general kernel, a frame too short to shard, cfg5's 2x2 supersampling and the
+    column samples re-traced inside the tiles), the general kernel, a frame too short to shard, cfg5's 2x2 supersampling and the
     two-pass 3x3 one; every case twice with a growing frame (the per-device buffers are re-allocated on the right device)."""
     import hashlib
     import os
@@ -811,7 +811,7 @@ def test_soak_seeds_on_exact_coincidences(lib, seed, degenerate):
     frame (centre-row rays have dy == 0 exactly; a refraction at refract_index 1 keeps or loses that exact zero depending
     on the last bit of the reference's own cosi, and a checker / texel boundary sits exactly on the plane), and a light
     exactly ON a sphere's surface (`t < light_len` between equal numbers).  Both are coin flips inside the reference's own
-    arithmetic; the library now renders them with the operation-for-operation kernel (centre row / column fix-up launches,
+    arithmetic; the library now renders them with the operation-for-operation kernel (the list-driven second launch for the centre row / column,
     rt_scene_dev::needs_strict), so: product path <= 1 LSB everywhere, and the strict kernel bit-identical as before."""
     scene, w, h = _soak_scene(seed, degenerate)
     blob = rt_host.flatten_scene(scene)

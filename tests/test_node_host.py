@@ -45,6 +45,7 @@ def test_node_render_matches_reference_frames(built):
         assert f["type"] == "[object Uint8ClampedArray]", name
         assert f["diff"] <= 1, (name, f)
     assert out["constructed"] <= 1 and out["async"] <= 1
+    assert out["animation"] == {"frames": 3, "same": True, "distinct": True}
     into = out["into"]
     assert into["sameObject"] is True and into["pinned"] <= 1 and into["pageable"] <= 1 and into["stats"] == "number"
     assert "4*width*height" in into["wrongSize"]
