@@ -730,6 +730,12 @@ def main():
                     # summed over an SQ's SIMDs, so VALU is also given per SIMD) and per resident wave-cycle
                     fp64_measured["issue"] = {"valu_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"], 4),
                                               "valu_per_busy_cycle_per_simd": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"] / 4.0, 4),
+                                              # what bounds the kernel: a 64-wide wave's VALU instruction occupies its 16-lane SIMD for 4 cycles.
+                                              # (a) against the SQ's own busy cycles (SQ_BUSY_CYCLES sums 32 instances - one per shader engine of each
+                                              # XCD, 32 SIMDs each - SQ_ACTIVE_INST_VALU counts issued instructions); (b) against this run's kernel_ms
+                                              # at the 2.4 GHz peak clock (a lower bound: under FP64 load the part clocks lower)
+                                              "valu_busy_frac_of_sq_busy_cycles": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (pmc["SQ_BUSY_CYCLES"] * 32.0), 4),
+                                              "valu_busy_frac_at_peak_clock": round(pmc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * kernel_ms * 1e-3 * 2.4e9), 4),
                                               "scalar_per_busy_cycle": round(pmc["SQ_ACTIVE_INST_SCA"] / pmc["SQ_BUSY_CYCLES"], 4),
                                               "any_per_wave_cycle": round(pmc["SQ_ACTIVE_INST_ANY"] / pmc["SQ_WAVE_CYCLES"], 4) if pmc.get("SQ_WAVE_CYCLES") else None,
                                               "counters": {k: pmc[k] for k in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY") if k in pmc}}
