@@ -129,6 +129,7 @@ struct rt_scene_dev {
   bool cull_in_lds;
   size_t lds_image_bytes;        // of one ordering
   uint64_t cam_gen = 1;          // bumped when the camera moves: launch tables and mark counts of an older camera are stale
+  uint32_t renders_with_camera = 0;   // product launches since the camera last moved (or the upload): many-sphere scenes get their shadow masks from the second on
   hipStream_t last_stream = nullptr;     // the stream of the scene's last launch; several: launches of this scene are in flight on more than one
   bool any_launch = false, several_streams = false;
   hipStream_t cam_stream = nullptr;      // the stream the camera block was last written on, and the event behind that copy
@@ -615,6 +616,7 @@ extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], cons
   memcpy(s->host_blob.data(), &nh, sizeof nh);
   camera_decisions(s);
   s->cam_gen++;
+  s->renders_with_camera = 0;
   // the block is staged now and copied by the next launch of the scene, on that launch's stream, together with what else that
   // launch has to copy (a launch table's parameters): one small kernel
   if (s->cam_pending) s->cam_pending->used = false;         // (a move nobody rendered: its slot is free again)
@@ -1161,7 +1163,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // per block and light, the spheres that can shadow a primary hit of the block at all, and the block's primary candidates;
     // needs every lit primary hit to lie on a loop sphere, i.e. no enclosing sphere or a flat one
     static const bool no_shadow_masks = RT_TEST_ENV("RT_NO_SHADOW_MASKS") != nullptr;   // A/B switch (test build)
-    const bool shadow_masks = !count && !no_shadow_masks && (s->enclosing == ~0u || s->enclosing_flat);
+    // Many spheres (more than 16 in the loops: a light's set is "empty or not"): the masks cost the table build ten times what
+    // they save ONE frame (64 spheres at 3840x2160: 0.33 ms of a 0.36 ms build against 0.013 ms of a 0.11 ms trace; few spheres:
+    // 0.011 against 0.020: profiles/r03_ab_log.md section 3) - the first frame from a camera is rendered from a table without
+    // them, a camera that stays gets the full table with its second frame.  (The picture is the same either way: masks only prune.)
+    const bool masks_pay = L.n_loop <= 16u || s->renders_with_camera >= 1u;
+    if (!count) s->renders_with_camera++;
+    const bool shadow_masks = !count && !no_shadow_masks && masks_pay && (s->enclosing == ~0u || s->enclosing_flat);
     const bool name_candidates = !count && !no_shadow_masks;
     const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
                                   shadow_masks, name_candidates, (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u), stream);
