@@ -136,7 +136,7 @@ def main():
             out[k] = {"off_by_one_channel_fraction": T["off_by_one"] / max(T["channels"], 1), "flipped_pixels": T["flipped_pixels"],
                       "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
                       "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"]),
-                      "exact_samples": T["exact_samples"]}
+                      "exact_samples": T["exact_samples"], "frames_that_differ_between_the_table_without_and_with_shadow_masks": T.get("table_mismatches", 0)}
         text = json.dumps(out, indent=1)
         if args.out:
             open(args.out, "w").write(text)
@@ -169,6 +169,14 @@ def main():
                 tot[name]["exact_samples"] += st.exact_samples     # samples the second, list-driven strict launch traced again
                 host = C.create_string_buffer(n_px * 4)
                 assert lib.rt_copy_to_host(0, host, d, n_px * 4) == 0
+                if name == "fma" and len(scene["objects"]) > 16:
+                    # many spheres: the first frame from a camera comes from a launch table without shadow masks, the second from the full
+                    # table (rt_api.hip: renders_with_camera) - the second is the one compared below, and the two must be the same bytes
+                    first = host.raw
+                    r.render_tiles(w, h, d, tiles, flags=flags, want_stats=True)
+                    assert lib.rt_copy_to_host(0, host, d, n_px * 4) == 0
+                    if host.raw != first:
+                        tot[name]["table_mismatches"] = tot[name].get("table_mismatches", 0) + 1
                 got = np.frombuffer(host.raw, dtype=np.uint8).reshape(n_px, 4).astype(np.int16)
                 diff = np.abs(got - want)
                 T = tot[name]
