@@ -84,7 +84,7 @@ struct rt_launch {
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
   uint32_t *out_frames[RT_MAX_SCATTER];
   // Launch table of the product kernel (rt_api.hip: dispatch_order): workgroup b of the flat grid renders the tile described by
-  // entry b = {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band}; the host lists the tiles
+  // entry b = {tile_x | rows_valid << 11 | first frame row << 15, first row in the output band}; the table build (rt_tables_gpu.hip) lists the tiles
   // dearest first, so that a launch ends on cheap tiles.  The strict kernel runs on the plain 2-D grid and ignores it.
   const uint32_t *order;             // the entries; the four words in front of them are the table's header {entries, ceil(entries / 8), 0, 0}
   uint32_t order_n8;                 // ceil(BLOCKS / 8): entry of workgroup b sits at (b % 8) * order_n8 + b / 8 (one contiguous part per XCD)

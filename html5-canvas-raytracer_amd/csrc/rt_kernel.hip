@@ -461,7 +461,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
   else { const uint32_t q = lane >> 2; P.sub = lane & 3u; P.px = tile_x * RT_TILE_W + wave * 8u + (q & 7u); P.trow = q >> 3; }
   P.frow = frow0 + P.trow;
   P.lrow = (e1 & 0xffffffu) + P.trow;
-  P.sky = (e1 >> 31) != 0u;                            // workgroup-uniform: no sphere can show in these blocks (rt_tables.cpp) ...
+  P.sky = (e1 >> 31) != 0u;                            // workgroup-uniform: no sphere can show in these blocks (rt_block.h) ...
   P.run = ((e1 >> 24) & 127u) + 1u;                    // ... a run of this many 32-pixel blocks, starting at tile_x
   P.cand = e4.w;                                       // the (at most two) loop spheres the block's primary rays can meet (count << 16 | second << 8 | first), or 0: cull
   P.rows_valid = rows_valid;                           // wave-uniform: rows of the block inside its tile and the frame
@@ -472,7 +472,7 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
 
 #if !RT_STRICT
 // Word 2 of this workgroup's launch-table entry: per light, the 16-bit set of loop-order spheres that can shadow a primary hit of
-// its block (rt_tables.cpp), or ~0u.  Read again where it is used - the primary node's lighting - instead of being kept in a
+// its block (rt_block.h), or ~0u.  Read again where it is used - the primary node's lighting - instead of being kept in a
 // scalar register across the cull and the search (the kernel has none to spare).
 __device__ __forceinline__ uint32_t rt_entry_shadow_masks(const rt_launch &L) {
   const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
@@ -641,7 +641,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         // kernel uses it too (with the reference's own discriminant for the survivors) and stays bit-identical.
         [[maybe_unused]] const geom_kptr ga = (geom_kptr)L.geom_cam;
 #if !RT_STRICT
-        // A block for which the host names at most two spheres its primary rays can meet at all (word 3 of its table entry;
+        // A block for which the table names at most two spheres its primary rays can meet at all (word 3 of its entry;
         // a floor block names the floor) tests those and skips the cull.
         if (cand_host != 0u) {                           // count << 16 | second << 8 | first (loop indices, ascending)
           { const uint32_t i = cand_host & 255u; const rt_geom g0 = RT_LOAD(ga, i); RT_ANCHORED(i, g0) }
@@ -1052,7 +1052,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #endif
 #if !RT_STRICT
             // Primary hits of a block whose table entry says that NO sphere can stand between the block's hit points and light k
-            // (rt_tables.cpp, shadow masks; most floor blocks): neither grid nor scan.
+            // (rt_block.h, shadow masks; most floor blocks): neither grid nor scan.
             bool no_occluder = false;
             if constexpr (!COUNT) no_occluder = primary_node && k < 2u && ((smask >> (16u * k)) & 0xffffu) == 0u;
             if (no_occluder) {
@@ -1423,7 +1423,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #endif
   double rgb[3];
   uint32_t cnt[3] = {0u, 0u, 0u};
-  // A workgroup the host marked as showing no sphere (rt_tables.cpp: the cull's own comparisons, made once for the workgroup's
+  // A workgroup the table build marked as showing no sphere (rt_block.h: the cone test, made once for the workgroup's
   // box) stores the background constant: no staging, no barrier, no ray, no cull.  (The staging loads issued above are simply
   // never waited for.)  45 % of the headline's workgroups.
   if (P0.sky) {
@@ -1515,7 +1515,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     packed += __shfl_xor(packed, 2);
     rgbw = (((packed & 1023u) + 2u) >> 2) | ((((packed >> 10) & 1023u) + 2u) >> 2 << 8) | ((((packed >> 20) & 1023u) + 2u) >> 2 << 16);
   }
-  // A sky entry of the launch table stands for a RUN of consecutive 32-pixel blocks of one row block (rt_tables.cpp): the
+  // A sky entry of the launch table stands for a RUN of consecutive 32-pixel blocks of one row block (rt_tables_gpu.hip): the
   // workgroup stores the same constant into each of them; every other workgroup stores its one block.
 #if RT_STRICT
   const uint32_t n_run = 1u;
