@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--degenerate-lights", action="store_true", help="also place lights at the centres of the ground/sky spheres ([0,0,0] is ON the ground sphere)")
     ap.add_argument("--windowed", action="store_true", help="narrow cones: each scene as two 8-row tiles of a 3840x2160 or 7680x4320 frame (the launch table's "
                     "sky blocks, shadow masks and candidates at the headline's block size of ~0.5 degrees)")
+    ap.add_argument("--sky-parts", action="store_true", help="also put every frame together the multi-GPU way: 2-4 senders' interleaved 8-row tiles without the "
+                    "sky blocks (RT_FLAG_NO_SKY) plus the owner's fill (RT_FLAG_SKY_ONLY), in one buffer; must be the plain frame's bytes")
     args = ap.parse_args()
     lib = rt_host.load_library()
     assert lib.rt_init(1) == 0, lib.rt_last_error()
@@ -136,7 +138,8 @@ def main():
             out[k] = {"off_by_one_channel_fraction": T["off_by_one"] / max(T["channels"], 1), "flipped_pixels": T["flipped_pixels"],
                       "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
                       "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"]),
-                      "exact_samples": T["exact_samples"], "frames_that_differ_between_the_table_without_and_with_shadow_masks": T.get("table_mismatches", 0)}
+                      "exact_samples": T["exact_samples"], "frames_that_differ_between_the_table_without_and_with_shadow_masks": T.get("table_mismatches", 0),
+                      "frames_put_together_from_sky_parts_that_differ": T.get("sky_part_mismatches", 0)}
         text = json.dumps(out, indent=1)
         if args.out:
             open(args.out, "w").write(text)
@@ -169,6 +172,18 @@ def main():
                 tot[name]["exact_samples"] += st.exact_samples     # samples the second, list-driven strict launch traced again
                 host = C.create_string_buffer(n_px * 4)
                 assert lib.rt_copy_to_host(0, host, d, n_px * 4) == 0
+                if args.sky_parts and not rows:
+                    import shard
+                    plain = host.raw
+                    G = 2 + seed % 3
+                    plan = shard.TilePlan(w, h, 8, G)
+                    assert lib.rt_memset_device(0, d, 0, n_px * 4) == 0
+                    for g in range(G):
+                        r.render_scatter(w, h, [d], rt_host.RtTiles(*plan.rt_tiles(g)), flags=flags | rt_host.RT_FLAG_NO_SKY, want_stats=True)
+                    r.render_scatter(w, h, [d], rt_host.RtTiles(h, 0, 1, 1), flags=flags | rt_host.RT_FLAG_SKY_ONLY, want_stats=True)
+                    assert lib.rt_copy_to_host(0, host, d, n_px * 4) == 0
+                    if host.raw != plain:
+                        tot[name]["sky_part_mismatches"] = tot[name].get("sky_part_mismatches", 0) + 1
                 if name == "fma" and len(scene["objects"]) > 16:
                     # many spheres: the first frame from a camera comes from a launch table without shadow masks, the second from the full
                     # table (rt_api.hip: renders_with_camera) - the second is the one compared below, and the two must be the same bytes
