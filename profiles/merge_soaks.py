@@ -13,6 +13,8 @@ for k in ("fma", "strict"):
     m[k] = {"flipped_pixels": sum(p[k]["flipped_pixels"] for p in parts), "worst_channel_difference": max(p[k]["worst_channel_difference"] for p in parts),
             "off_by_one_channel_fraction": sum(p[k]["off_by_one_channel_fraction"] * p["pixels_per_kernel"] * 4 for p in parts) / max(ch, 1),
             "scenes_with_flips": sum((p[k]["scenes_with_flips"] for p in parts), []), "exact_samples": sum(p[k].get("exact_samples", 0) for p in parts),
+            "camera_moves": sum(p[k].get("camera_moves", 0) for p in parts), "camera_moves_refused": sum(p[k].get("camera_moves_refused", 0) for p in parts),
+            "moved_frames_that_differ_from_a_fresh_upload": sum(p[k].get("moved_frames_that_differ_from_a_fresh_upload", 0) for p in parts),
             "frames_put_together_from_sky_parts_that_differ": sum(p[k].get("frames_put_together_from_sky_parts_that_differ", 0) for p in parts),
             "frames_that_differ_between_the_table_without_and_with_shadow_masks": sum(p[k].get("frames_that_differ_between_the_table_without_and_with_shadow_masks", 0) for p in parts)}
 json.dump(m, open(out, "w"), indent=1)

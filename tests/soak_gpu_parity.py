@@ -117,6 +117,8 @@ def main():
                     "sky blocks, shadow masks and candidates at the headline's block size of ~0.5 degrees)")
     ap.add_argument("--sky-parts", action="store_true", help="also put every frame together the multi-GPU way: 2-4 senders' interleaved 8-row tiles without the "
                     "sky blocks (RT_FLAG_NO_SKY) plus the owner's fill (RT_FLAG_SKY_ONLY), in one buffer; must be the plain frame's bytes")
+    ap.add_argument("--camera-moves", action="store_true", help="after its frame every scene gets two random camera moves (rt_scene_set_camera: the launch "
+                    "table rebuilt on the GPU, mark counts forgotten); each moved frame must be the bytes a fresh upload of the moved scene renders")
     args = ap.parse_args()
     lib = rt_host.load_library()
     assert lib.rt_init(1) == 0, lib.rt_last_error()
@@ -139,7 +141,9 @@ def main():
                       "flipped_pixel_fraction": T["flipped_pixels"] / max(pixels, 1), "worst_channel_difference": T["worst"],
                       "scenes_with_flips": T["scenes_with_flips"][:40], "n_scenes_with_flips": len(T["scenes_with_flips"]),
                       "exact_samples": T["exact_samples"], "frames_that_differ_between_the_table_without_and_with_shadow_masks": T.get("table_mismatches", 0),
-                      "frames_put_together_from_sky_parts_that_differ": T.get("sky_part_mismatches", 0)}
+                      "frames_put_together_from_sky_parts_that_differ": T.get("sky_part_mismatches", 0),
+                      "camera_moves": T.get("camera_moves", 0), "camera_moves_refused": T.get("camera_moves_refused", 0),
+                      "moved_frames_that_differ_from_a_fresh_upload": T.get("camera_move_mismatches", 0)}
         text = json.dumps(out, indent=1)
         if args.out:
             open(args.out, "w").write(text)
@@ -203,6 +207,35 @@ def main():
                 if flips:
                     T["scenes_with_flips"].append({"seed": seed, "w": w, "h": h, "pixels": flips, "spheres": len(scene["objects"]),
                                                    "segs": scene["segs"], "ss": scene["supersample"]})
+                # (last: the moves leave the resident scene with another camera)
+                if args.camera_moves and not rows:
+                    crng = random.Random(seed * 31 + (7 if flags else 3))
+                    for _ in range(2):
+                        cam = look_at([crng.uniform(-6, 6), crng.uniform(0.2, 5), crng.uniform(-6, 9)], [crng.uniform(-2, 2), crng.uniform(0, 2.5), crng.uniform(-2, 2)], [0.0, 1.0, 0.0])
+                        moved = dict(scene, camera=cam)
+                        try:
+                            r.set_camera(cam)
+                        except rt_host.RtError:
+                            tot[name]["camera_moves_refused"] = tot[name].get("camera_moves_refused", 0) + 1      # (across the enclosing sphere: upload again)
+                            break
+                        r.render_tiles(w, h, d, tiles, flags=flags, want_stats=True)
+                        moved_host = C.create_string_buffer(n_px * 4)
+                        assert lib.rt_copy_to_host(0, moved_host, d, n_px * 4) == 0
+                        r2 = rt_host.Renderer(rt_host.flatten_scene(moved), 0, lib)
+                        try:
+                            r2.render_tiles(w, h, d, tiles, flags=flags, want_stats=True)
+                            fresh_host = C.create_string_buffer(n_px * 4)
+                            assert lib.rt_copy_to_host(0, fresh_host, d, n_px * 4) == 0
+                        finally:
+                            r2.close()
+                        tot[name]["camera_moves"] = tot[name].get("camera_moves", 0) + 1
+                        if moved_host.raw != fresh_host.raw:
+                            tot[name]["camera_move_mismatches"] = tot[name].get("camera_move_mismatches", 0) + 1
+                    try:
+                        r.set_camera(scene["camera"])               # back where the scene was drawn: the other kernel's frame is next
+                    except rt_host.RtError:
+                        r.close()
+                        r = rt_host.Renderer(blob, 0, lib)
         finally:
             lib.rt_free_device(0, d)
             r.close()
