@@ -18,11 +18,15 @@
 // Shadow grid (product kernel, scenes with more than RT_SGRID_MIN_LOOP spheres in the loops): cells per axis of a
 // light's projective view of the scene; see build_shadow_grid in rt_tables.cpp for the buffer layout.
 #define RT_MAX_SCATTER 16u          /* frames of one rt_render_scatter_device call */
+#ifndef RT_SGRID
 #define RT_SGRID 32u
+#endif
 #define RT_SGRID_MIN_LOOP 12u
 // Bounce table (same scenes): directions are binned on a cube map of RT_BGRID x RT_BGRID cells per face; see
 // build_bounce_table in rt_tables.cpp.
+#ifndef RT_BGRID
 #define RT_BGRID 8u
+#endif
 #define RT_BTABLE_MIN_LOOP 24u     /* measured: +10 % on the 64-sphere scene, -2 % on the reference's 14-sphere scene */
 #define RT_BCELLS (6u * RT_BGRID * RT_BGRID)
 

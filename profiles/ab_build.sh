@@ -15,7 +15,7 @@ COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -f
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=0 -ffp-contract=fast -c $SRC/rt_kernel.hip -o $T/kf.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -DRT_STRICT=1 -ffp-contract=off -c $SRC/rt_kernel.hip -o $T/ks.o &
 /opt/rocm/bin/hipcc $COMMON $APITESTING $FLAGS -c $SRC/rt_api.hip -o $T/api.o &
-/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -Wall -I$SRC -x c++ -c $SRC/rt_tables.cpp -o $T/tables.o &
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -Wall -I$SRC $FLAGS -x c++ -c $SRC/rt_tables.cpp -o $T/tables.o &
 /opt/rocm/bin/hipcc $COMMON $FLAGS -ffp-contract=off -c $SRC/rt_tables_gpu.hip -o $T/tables_gpu.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/librt_hip_$NAME.so $T/api.o $T/tables.o $T/tables_gpu.o $T/kf.o $T/ks.o -ldl
