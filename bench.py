@@ -2,12 +2,15 @@
 """bench.py — BASELINE.json's metric on BASELINE.json's configs.
 
     python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg5]
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: started bare it launches `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` itself, as a
+     child process, and relays rank 0's JSON line; started under torch.distributed.run it is one of the ranks)
 
 --config cfg3 (default, the headline): BASELINE configs[2] — 3840x2160, the 8-sphere "H8" scene, 2 lights, depth 3.
     N = 1: a step is ONE kernel launch writing one frame (the hot path, main.js:184-199 + :216-451, through the C ABI's
-    rt_render_tiles_device).  N > 1: a step is a BATCH of N frames, frame f ends up whole on rank f (weak scaling: per-GPU
-    work per step is one frame's worth of pixels at every N).
+    rt_render_tiles_device).  N > 1: a step is ONE frame, row-tiled over the N ranks and whole on rank 0 after one collective /
+    barrier - north_star's form, strong scaling: `value`, with `efficiency_vs_n1` and `predicted` (what the links allow, stated
+    per N).  The batch form (N frames per step, frame f whole on rank f, every directed link in use; weak scaling) is measured
+    in the same run and rides in the line as `batch_mode`.
 --config cfg4: BASELINE configs[3] — ONE 7680x4320 H8 frame per step, row-tiled over the N ranks and whole on rank 0 after
     one collective / barrier (strong scaling: the frame is fixed, per-GPU work shrinks with N).
 --config cfg5: BASELINE configs[4] — ONE 16384x16384 frame, 2x2 supersample, 64 spheres, depth 5, the same way.
@@ -315,6 +318,49 @@ def cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch
     return out
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started bare: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>` as a child
+    (one rank per GPU; rendezvous on 127.0.0.1, a free port), hand its stdout - rank 0's one JSON line - on, return its exit code.
+    Nothing in this process has initialised the GPU by now (importing this file and parsing arguments does not), so the ranks start clean."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # stderr goes straight through
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in lines[-1:]:
+        sys.stdout.write(l + "\n")
+    sys.stdout.flush()
+    if r.returncode == 0 and not lines:
+        print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
+XGMI_GBS_PER_DIRECTION = 64.0       # what a kernel's stores / an RCCL copy sustain over ONE xGMI link in one direction (153 GB/s per link both ways, nominal)
+LAUNCH_FLOOR_MS = 0.006             # a launch's fixed cost on the stream (cfg1's 256x256 frame: 0.007 ms)
+
+
+def predicted_single_frame(n, w, h, kernel_ms_n1, bytes_per_pixel, sky_fraction):
+    """What ONE frame row-tiled over n GPUs and put together on rank 0 should cost per step, stated BEFORE the first run on real links, so
+    that the run is judged against an expectation: every rank renders 1/n of the frame (its kernel time shrinks to 1/n of the one-GPU
+    kernel plus a launch's fixed cost), rank g > 0 ships its share over ITS OWN link to rank 0 (xGMI is point to point), steps are
+    pipelined, so a step costs the larger of the two.  All of rank 0's inbound bytes land in one GPU's links: the form is link-bound
+    by construction at every n for frames a GPU renders faster than a link carries them."""
+    render = kernel_ms_n1 / n + LAUNCH_FLOOR_MS
+    link = (w * h * bytes_per_pixel * (1.0 - sky_fraction) / n) / (XGMI_GBS_PER_DIRECTION * 1e9) * 1e3
+    step = max(render, link)
+    return {"ms_per_step": round(step, 4), "render_ms": round(render, 4), "link_ms": round(link, 4),
+            "mpixel_per_s": round(w * h / step / 1e3, 1), "efficiency_vs_n1": round((kernel_ms_n1 / step) / n, 3),
+            "bound": "link into rank 0" if link >= render else "render"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +380,11 @@ def main():
     w, h = args.width or cfg_w, args.height or cfg_h
     if args.config != "cfg3" and "--steps" not in sys.argv:
         args.steps = 400 if args.config == "cfg4" else 20
+
+    # `python3 bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves.  A CHILD process (never an exec),
+    # started before anything here has touched the GPU; its one JSON line is relayed, its exit code is ours.
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a "Hostname / Librccl path" banner
     # on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
@@ -356,6 +407,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if world > 1 and os.environ.get("RT_BENCH_REHEARSE") != "1" and torch.cuda.device_count() < world:      # (counting devices initialises nothing)
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); RT_BENCH_REHEARSE=1 rehearses the N>1 control flow on one GPU (never a measurement)"
+                         % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the render path has no CPU fallback")
     # RT_BENCH_REHEARSE=1: rehearsal of the N>1 control flow on a ONE-GPU box — every rank shares GPU 0 and
@@ -893,6 +947,17 @@ def main():
                                    "bytes_sent_per_rank_per_step": plan.band_bytes if single else (world - 1) * plan.band_bytes,
                                    "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
                                    "steps_per_collective": every}
+            if n1_mpix and single:
+                # the expectation this form is judged against (stated per N, so that the first run on real links has something to be held to)
+                k1 = w * h / n1_mpix / 1e3                                  # one GPU's ms per frame, this run
+                bpp = channels
+                skyf = out["exchange"].get("sky_fraction_of_this_ranks_blocks", 0.0) if (mode["p2p"] and sky_out) else out["exchange"].get("sky_fraction_left_out", 0.0)
+                out["predicted"] = {"model": "step = max(one GPU's frame time / N + %.3f ms launch floor, this rank's share of the frame's bytes / one xGMI link at %.0f GB/s per direction); "
+                                             "steps pipelined; rank 0's inbound links carry (N-1)/N of every frame, each sender on its own link" % (LAUNCH_FLOOR_MS, XGMI_GBS_PER_DIRECTION),
+                                    "bytes_per_pixel_on_the_link": bpp, "sky_fraction_left_out": round(skyf, 4), "one_gpu_ms_per_frame": round(k1, 4),
+                                    "per_n": {str(g): predicted_single_frame(g, w, h, k1, bpp, skyf) for g in (2, 4, 8)}}
+                if str(world) in out["predicted"]["per_n"] and not rehearse:
+                    out["predicted"]["measured_over_predicted_at_this_n"] = round(out["ms_per_step"] / out["predicted"]["per_n"][str(world)]["ms_per_step"], 3)
             if world == 1 and not args.no_cold and not args.strict_fp and os.environ.get("RT_BENCH_CHILD") != "1" and w * h <= 7680 * 4320:
                 try:
                     out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(64, min(args.steps, 512))))
@@ -917,19 +982,23 @@ def main():
         return result, parity_ok, max_lsb
 
 
-    single_default = single
-    out, parity_ok, max_lsb = run(single_default)
-    # cfg3 on several GPUs: the batch line above is what BASELINE's metric scales weakly; north_star's own form - ONE 3840x2160 frame
-    # row-tiled over the ranks, whole on rank 0 - is measured as well and rides in the same JSON line
-    if world > 1 and args.config == "cfg3" and not single_default and os.environ.get("RT_BENCH_NO_SINGLE_FRAME") != "1":
-        out2, ok2, lsb2 = run(True)
-        parity_ok, max_lsb = parity_ok and ok2, max(max_lsb, lsb2)
+    # cfg3 on several GPUs.  The headline is north_star's own form: ONE 3840x2160 frame per step, row-tiled over the ranks, whole on rank 0
+    # after one collective / barrier (strong scaling: the frame is fixed).  The batch form - N frames per step, frame f whole on rank f,
+    # every directed link in use - is measured first and rides in the same JSON line as `batch_mode` (weak scaling; never the headline).
+    batch = None
+    if world > 1 and args.config == "cfg3" and not single and os.environ.get("RT_BENCH_NO_BATCH") != "1":
+        batch = run(False)
+    out, parity_ok, max_lsb = run(True if (world > 1 and args.config == "cfg3") else single)
+    if batch is not None:
+        out_b, ok_b, lsb_b = batch
+        parity_ok, max_lsb = parity_ok and ok_b, max(max_lsb, lsb_b)
         if rank == 0:
-            out["single_frame"] = {k: out2[k] for k in ("value", "unit", "ms_per_step", "scaling", "max_lsb_vs_reference_rows", "parity_ok", "n1_reference", "efficiency_vs_n1", "exchange") if k in out2}
-            out["single_frame"]["workload"] = out2["config"]["workload"]
+            out["batch_mode"] = {k: out_b[k] for k in ("value", "unit", "ms_per_step", "scaling", "max_lsb_vs_reference_rows", "parity_ok", "n1_reference", "efficiency_vs_n1", "exchange") if k in out_b}
+            out["batch_mode"]["workload"] = out_b["config"]["workload"]
+            out["batch_mode"]["frames_per_step"] = out_b["config"]["frames_per_step"]
             for k in ("plan_note", "plan_calibration_ms_per_step"):
-                if k in out2["config"]:
-                    out["single_frame"][k] = out2["config"][k]
+                if k in out_b["config"]:
+                    out["batch_mode"][k] = out_b["config"][k]
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
