@@ -28,6 +28,9 @@
 extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_retrace(const rt_launch *, int, int, unsigned, hipStream_t);
+extern "C" int rt_scratch_trace_fast(int, int, int, int, size_t *);
+extern "C" int rt_scratch_trace_strict(int, int, int, int, size_t *);
+extern "C" int rt_scratch_retrace(int, int, size_t *);
 
 using namespace rt_tables;   // the host-built tables (pure host logic, rt_tables.cpp)
 
@@ -71,6 +74,11 @@ struct device_state {
   // (upload + table builds cost 0.1 ms for 8 spheres and 1.8 ms for 64, against a 0.7 ms frame)
   struct rt_scene_dev *cached_scene = nullptr;
   std::vector<uint8_t> cached_blob;
+  // scratch_guard: wave slots of the device (CUs x waves per CU) and, per stream, the largest per-lane scratch figure whose reservation
+  // has been held against the free device memory
+  size_t wave_slots = 0;
+  struct scratch_seen { hipStream_t stream; size_t per_lane; };
+  std::vector<scratch_seen> scratch_checked;
 };
 
 struct lib_state {
@@ -105,6 +113,61 @@ int ensure_device(int d) {
   return RT_OK;
 }
 
+// Kernels with a private segment (the general kernel's park stack: 3472 B per lane; the strict kernels' recursion stack) make the
+// runtime reserve scratch memory: bytes per lane x 64 lanes x the wave slots the dispatch can occupy (at most CUs x waves per CU =
+// 8192 on MI355X: 1.8 GB for the general kernel).  When that reservation cannot be met the HIP runtime does not return an error from
+// the launch: the queue's error callback ABORTS the process (profiles/r04_scratch_refusal.log).  So every launch path of a kernel that
+// needs scratch holds the figure against the free device memory first - once per (stream, larger figure): later launches reuse the
+// queue's scratch - and the library returns RT_ERR_NOMEM with the numbers instead of reaching that abort.
+int scratch_guard(device_state &D, hipStream_t stream, size_t per_lane, uint64_t waves_in_grid, const char *what) {
+#ifdef RT_TESTING
+  bool pretend = false;
+  if (const char *q = getenv("RT_TEST_SCRATCH_PER_LANE")) { per_lane = (size_t)strtoull(q, nullptr, 10); pretend = true; }    // as if the kernel asked for this much
+#else
+  const bool pretend = false;
+#endif
+  if (per_lane == 0) return RT_OK;
+  std::lock_guard<std::mutex> lk(G.dev_mu);
+  if (!pretend) for (const device_state::scratch_seen &c : D.scratch_checked) if (c.stream == stream && c.per_lane >= per_lane) return RT_OK;
+  if (!D.wave_slots) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, D.hip_id));
+    D.wave_slots = (size_t)p.multiProcessorCount * (size_t)(p.maxThreadsPerMultiProcessor / 64);
+    if (!D.wave_slots) D.wave_slots = 8192;
+  }
+  const uint64_t slots = waves_in_grid < D.wave_slots ? waves_in_grid : D.wave_slots;
+  const uint64_t reservation = (uint64_t)per_lane * 64u * slots;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const uint64_t margin = (uint64_t)64 << 20;
+  if (reservation + margin > free_b)
+    return fail(RT_ERR_NOMEM, "%s needs %zu bytes of scratch per lane: the runtime reserves that for %llu wave slots = %llu bytes, and %zu of %zu bytes of device memory are free",
+                what, per_lane, (unsigned long long)slots, (unsigned long long)reservation, free_b, total_b);
+  if (!pretend) {
+    bool found = false;
+    for (device_state::scratch_seen &c : D.scratch_checked) if (c.stream == stream) { c.per_lane = per_lane; found = true; }
+    if (!found) { if (D.scratch_checked.size() >= 64u) D.scratch_checked.clear(); D.scratch_checked.push_back(device_state::scratch_seen{stream, per_lane}); }
+  }
+  return RT_OK;
+}
+
+// per-lane scratch of a kernel instantiation, from its code object (asked once per instantiation)
+int kernel_scratch(bool strict, bool retrace, int refract, int count, int ss2, int grid_variant, size_t *out) {
+  static std::mutex mu;
+  static size_t cache[3][2][2][2][2];
+  static bool have[3][2][2][2][2];
+  const int k = retrace ? 2 : (strict ? 1 : 0), c = retrace ? 0 : (count ? 1 : 0), g = (retrace || strict) ? 0 : (grid_variant ? 1 : 0);
+  std::lock_guard<std::mutex> lk(mu);
+  if (!have[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g]) {
+    size_t b = 0;
+    const int e = retrace ? rt_scratch_retrace(refract, ss2, &b) : (strict ? rt_scratch_trace_strict(refract, count, ss2, 0, &b) : rt_scratch_trace_fast(refract, count, ss2, grid_variant, &b));
+    if (e != 0) return fail(RT_ERR_DEVICE, "hipFuncGetAttributes: %s", hipGetErrorString((hipError_t)e));
+    cache[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g] = b; have[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g] = true;
+  }
+  *out = cache[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g];
+  return RT_OK;
+}
+
 }  // namespace
 
 struct rt_scene_dev {
@@ -129,7 +192,10 @@ struct rt_scene_dev {
   bool cull_in_lds;
   size_t lds_image_bytes;        // of one ordering
   uint64_t cam_gen = 1;          // bumped when the camera moves: launch tables and mark counts of an older camera are stale
-  uint32_t renders_with_camera = 0;   // product launches since the camera last moved (or the upload): many-sphere scenes get their shadow masks from the second on
+  uint32_t renders_with_camera = 0;   // product launches since the camera last moved (or the upload)
+  // ... and per (frame size, tile set, sky part): many-sphere scenes get their shadow masks with the SECOND frame of a kind from a camera
+  struct camera_use { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles, part; uint64_t cam_gen; uint32_t uses; };
+  std::vector<camera_use> camera_uses;
   hipStream_t last_stream = nullptr;     // the stream of the scene's last launch; several: launches of this scene are in flight on more than one
   bool any_launch = false, several_streams = false;
   hipStream_t cam_stream = nullptr;      // the stream the camera block was last written on, and the event behind that copy
@@ -433,6 +499,10 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
         if (!(f0 >= 0.0 && f0 < 2147483648.0 && f1 >= 0.0 && f1 < 2147483648.0)) s->needs_strict_scene = true;
       }
     }
+    // The hot path's prefilter passes coordinates within 2^-20 of an integer to the precise test against flag_tol = RT_FLAG_T1 x this
+    // frequency: above 2^20 per unit u the tolerance would approach the prefilter's band (equal at 4.7e6) and the margin over the
+    // product kernel's own error in a coordinate (~1e-16 x frequency) would shrink with it.  Such scenes take the strict kernel.
+    if (fmaxq > 1048576.0) s->needs_strict_scene = true;
     s->flag_tol = RT_FLAG_T1 * fmaxq;
   }
   memset(s->lights, 0, sizeof s->lights);
@@ -528,26 +598,9 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   if (has_b) memcpy(host.data() + off_objs_b, s->host_objects_b.data(), NO * sizeof(rt_sphere));
   if (!sg.empty()) memcpy(host.data() + off_sg, sg.data(), sg.size() * sizeof(uint64_t));
   if (!bt.empty()) memcpy(host.data() + off_bt, bt.data(), bt.size() * sizeof(uint64_t));
-  // the LDS images' camera-independent part: [materials | texture descriptors]
-  auto fill_image = [&](uint8_t *dst, const rt_sphere *src) {
-    rt_mtl *mt = (rt_mtl *)dst;
-    for (uint32_t i = 0; i < NO; i++) {
-      const rt_sphere &o = src[i];
-      rt_mtl &m = mt[i];
-      memset(&m, 0, sizeof m);
-      memcpy(m.origin, o.origin, sizeof m.origin);
-      m.inv_r = o.reserved;                           // 1/r, patched above
-      memcpy(m.albedo, o.albedo, sizeof m.albedo);
-      m.specular_exponent = o.specular_exponent; m.refract_index = o.refract_index;
-      m.sampler_kind = o.sampler_kind; m.texture = o.texture;
-      if (o.sampler_kind == RT_SAMPLER_CHECKER) memcpy(m.c, o.checker_color, 6 * sizeof(double));
-      else memcpy(m.c, o.color, 3 * sizeof(double));
-      m.c[6] = o.checker_freq[0]; m.c[7] = o.checker_freq[1];
-    }
-    memcpy(dst + (size_t)NO * sizeof(rt_mtl), descs, sizeof descs);
-  };
-  uint8_t *img_host = host.data() + (s->cull_in_lds ? off_cam + up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) : off_img);
-  for (int ord = 0; ord < n_ord; ord++) fill_image(img_host + ord * s->lds_image_bytes, ord ? s->host_objects_b.data() : pob_a);
+  // the LDS images' camera-independent part: [materials | texture descriptors] (fill_camera_block below writes them again, with
+  // their cull rectangles, when they live in the camera block)
+  if (!s->cull_in_lds) for (int ord = 0; ord < n_ord; ord++) fill_lds_image(s, host.data() + off_img + ord * s->lds_image_bytes, ord);
   fill_camera_block(s, host.data() + off_cam);
   // ---- one allocation, one copy ----
   hipError_t e = hipMalloc((void **)&s->arena, s->arena_bytes);
@@ -1090,7 +1143,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   if (const char *fs = getenv("RT_FLAG_SCALE")) { L.flag_tol *= atof(fs); test_marks = true; }        // a wider boundary band, to exercise the second launch
   if (getenv("RT_MARK_ALL") || getenv("RT_EXACT_ALL") || no_fixup) test_marks = true;
 #endif
-  L.mark_flags = (RT_TEST_ENV("RT_MARK_ALL") ? RT_MARK_ALL : 0u) | (no_fixup ? RT_MARK_NEVER : 0u);
+  L.mark_flags = (RT_TEST_ENV("RT_MARK_ALL") ? RT_MARK_ALL : 0u) | (no_fixup ? RT_MARK_NEVER : 0u) | (RT_TEST_ENV("RT_TEST_MARK_STRIPES") ? RT_MARK_ZERO : 0u);
   L.marks_cap = RT_MARKS_CAP;
   L.textures = s->d_texdesc;
   L.texel_base = db;
@@ -1141,7 +1194,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   uint32_t marks_read_slot = 0;
   const uint32_t *marks_read = nullptr;                 // stats: where this launch's mark count can be read afterwards
   uint64_t centre_items = 0;
-  bool retraced_all = false;
+  bool retraced_all = false, overflowed_strict = false;
   if (strict_main && (flags & RT_FLAG_SKY_ONLY)) {
     // (the strict kernels know no sky blocks: the RT_FLAG_NO_SKY calls of such a launch store every pixel, this one none)
   } else if (strict_main) {
@@ -1150,6 +1203,11 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       hipError_t e = (hipError_t)rt_launch_small_copy(s->d_cam, cam->h, s->cam_bytes_used, nullptr, nullptr, 0u, stream);
       if (e == hipSuccess) e = camera_copied(s, cam, stream);
       if (e != hipSuccess) return fail(RT_ERR_DEVICE, "camera block: %s", hipGetErrorString(e));
+    }
+    {
+      size_t per_lane = 0;
+      if ((rc = kernel_scratch(true, false, s->refract, count, ss2, 0, &per_lane))) return rc;
+      if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.tiles_x * L.n_tiles * L.rb_per_tile * n_frames * (RT_WG_THREADS / 64u), "the strict trace kernel"))) return rc;
     }
     err = rt_launch_trace_strict(&L, s->refract, count, ss2, lds_for(true), stream);
   } else {
@@ -1167,12 +1225,30 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // they save ONE frame (64 spheres at 3840x2160: 0.33 ms of a 0.36 ms build against 0.013 ms of a 0.11 ms trace; few spheres:
     // 0.011 against 0.020: profiles/r03_ab_log.md section 3) - the first frame from a camera is rendered from a table without
     // them, a camera that stays gets the full table with its second frame.  (The picture is the same either way: masks only prune.)
-    const bool masks_pay = L.n_loop <= 16u || s->renders_with_camera >= 1u;
-    if (!count) s->renders_with_camera++;
-    const bool shadow_masks = !count && !no_shadow_masks && masks_pay && (s->enclosing == ~0u || s->enclosing_flat);
-    const bool name_candidates = !count && !no_shadow_masks;
+    // ("second frame" is counted per (frame size, tile set, sky part): the bands of one rt_render frame and the owner's sky fill
+    // are several launches of ONE frame, and all of them are first launches from a new camera)
+    const uint32_t sky_part = (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u);
+    uint32_t uses_before = 0;
+    if (!count) {
+      rt_scene_dev::camera_use *cu = nullptr;
+      for (rt_scene_dev::camera_use &c : s->camera_uses)
+        if (c.w == w && c.h == h && c.ss == (ss2 ? 2u : 1u) && c.tile_rows == tiles->tile_rows && c.tile_first == tiles->tile_first && c.tile_stride == tiles->tile_stride &&
+            c.n_tiles == tiles->n_tiles && c.part == sky_part) { cu = &c; break; }
+      if (!cu) {
+        if (s->camera_uses.size() >= 64u) s->camera_uses.erase(s->camera_uses.begin());
+        s->camera_uses.push_back(rt_scene_dev::camera_use{w, h, ss2 ? 2u : 1u, tiles->tile_rows, tiles->tile_first, tiles->tile_stride, tiles->n_tiles, sky_part, 0u, 0u});
+        cu = &s->camera_uses.back();
+      }
+      if (cu->cam_gen != s->cam_gen) { cu->cam_gen = s->cam_gen; cu->uses = 0u; }
+      uses_before = cu->uses++;
+      s->renders_with_camera++;
+    }
+    const bool masks_pay = L.n_loop <= 16u || uses_before >= 1u;
+    // (a table of nothing but sky runs is read by workgroups that store a constant: neither masks nor candidates)
+    const bool shadow_masks = !count && !no_shadow_masks && masks_pay && sky_part != 2u && (s->enclosing == ~0u || s->enclosing_flat);
+    const bool name_candidates = !count && !no_shadow_masks && sky_part != 2u;
     const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
-                                  shadow_masks, name_candidates, (flags & RT_FLAG_NO_SKY) ? 1u : ((flags & RT_FLAG_SKY_ONLY) ? 2u : 0u), stream);
+                                  shadow_masks, name_candidates, sky_part, stream);
     if (oi < 0) return RT_ERR_DEVICE;
     rt_scene_dev::order_entry &oe = s->orders[oi];
     L.order = oe.T.entries;
@@ -1199,6 +1275,28 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       }
     }
     L.marks = ms->d_marks; L.marks_slot = ms->slot;
+    const uint32_t known = test_marks ? 0u : known_value(ms->h_known, s->cam_gen);        // 0: not known (yet); else the frame's mark count + 1
+    // A frame KNOWN to mark more samples than the list holds (a legal scene can: every hit of a sphere whose sampler coordinate is
+    // an exact integer everywhere) would be traced twice in full, product kernel then rt_retrace over every sample: the strict
+    // kernel renders it once instead, the same bytes (the count stays known: nothing republishes it for this camera).
+    const bool overflow_known = known != 0u && known - 1u > RT_MARKS_CAP && !count;
+    if (overflow_known) {
+      if (!(flags & RT_FLAG_SKY_ONLY)) {              // (as every strict launch: a NO_SKY call stores every pixel, a SKY_ONLY call none)
+        rt_launch S = L;
+        S.order = nullptr; S.grid_x = S.grid_y = 0u;
+        bind_kernel(S, true);
+        size_t per_lane = 0;
+        if ((rc = kernel_scratch(true, false, s->refract, 0, ss2, 0, &per_lane))) return rc;
+        if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.tiles_x * L.n_tiles * L.rb_per_tile * n_frames * (RT_WG_THREADS / 64u), "the strict trace kernel"))) return rc;
+        err = rt_launch_trace_strict(&S, s->refract, 0, ss2, lds_for(true), stream);
+        overflowed_strict = true;
+      }
+    } else {
+    {
+      size_t per_lane = 0;
+      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane))) return rc;
+      if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
+    }
     err = rt_launch_trace_fast(&L, s->refract, count, ss2, lds_for(false), stream);
     // Centre row / centre column of a sample grid with an ODD number of rows / columns (supersample 2 makes it even).  The primary
     // rays there have a direction component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they
@@ -1216,7 +1314,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
     if (!ss2 && (w & 1u)) { F.centre_col = (w - 1u) / 2u; centre_items += (uint64_t)tiles->n_tiles * tiles->tile_rows * n_frames; }
     const bool retrace_all = RT_TEST_ENV("RT_EXACT_ALL") != nullptr && !no_fixup;
-    const uint32_t known = test_marks ? 0u : known_value(ms->h_known, s->cam_gen);        // 0: not known (yet); else the frame's mark count + 1
     const bool need = !no_fixup && !(flags & RT_FLAG_SKY_ONLY) && (known != 1u || centre_items != 0 || retrace_all);     // (a sky-only launch traces nothing; the centre lines belong to the calls that trace)
     if (err == 0 && need) {
       bind_kernel(F, true);                             // the scene in its own order, every sphere in the loops, the reference's own miss colour
@@ -1224,11 +1321,22 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       F.known_tag = (uint32_t)s->cam_gen;
       F.retrace_all = retrace_all ? 1u : 0u;
       retraced_all = retrace_all;
-      uint64_t n_wg = (centre_items + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;
+      // The grid.  Count known: its items and the centre lines.  Not known yet (the first frame from a camera): the list may hold up
+      // to RT_MARKS_CAP items or have overflowed - 256 workgroups (idle ones leave at once) walk an overflowed 3840x2160 frame at
+      // ~130 samples per lane, once; from the next frame on the count is known (and an overflow takes the strict kernel above).
+      uint64_t n_wg = ((known ? known - 1u : 0u) + centre_items + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;
+      if (!known && n_wg < 256u) n_wg = 256u;
       if (retrace_all) n_wg = ((uint64_t)tiles->n_tiles * tiles->tile_rows * w * n_frames + RT_WG_THREADS - 1) / RT_WG_THREADS;
-      err = rt_launch_retrace(&F, s->refract, ss2, (unsigned)(n_wg < 8192u ? n_wg : 8192u), stream);
+      if (n_wg > 8192u) n_wg = 8192u;
+      {
+        size_t per_lane = 0;
+        if ((rc = kernel_scratch(true, true, s->refract, 0, ss2, 0, &per_lane))) return rc;
+        if ((rc = scratch_guard(D, stream, per_lane, n_wg * (RT_WG_THREADS / 64u), "the list-driven strict launch (rt_retrace)"))) return rc;
+      }
+      err = rt_launch_retrace(&F, s->refract, ss2, (unsigned)n_wg, stream);
       marks_read = ms->d_marks; marks_read_slot = ms->slot;
       ms->slot ^= 1u;                                   // rt_retrace cleared the other counter: the next launch's
+    }
     }
   }
   if (err != 0) return fail(RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString((hipError_t)err));
@@ -1251,6 +1359,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       stats->rays = c[0]; stats->shadow_rays = c[1]; stats->sphere_tests = c[2];
     }
     // samples the second launch traced again: the marked ones (read back from the list's counter) and the odd grid's centre lines
+    if (overflowed_strict) stats->exact_samples = stats->pixels;      // the strict kernel rendered the call
     if (marks_read) {
       uint32_t n_marked = 0;
       HIP_TRY(hipMemcpy(&n_marked, marks_read + marks_read_slot, sizeof n_marked, hipMemcpyDeviceToHost));

@@ -58,8 +58,10 @@
 #endif
 #if RT_STRICT
 #define RT_LAUNCH_NAME rt_launch_trace_strict
+#define RT_SCRATCH_NAME rt_scratch_trace_strict
 #else
 #define RT_LAUNCH_NAME rt_launch_trace_fast
+#define RT_SCRATCH_NAME rt_scratch_trace_fast
 #endif
 
 // Register budget: minimum waves per SIMD the kernel must fit (second __launch_bounds__ argument).
@@ -859,7 +861,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         // again (the sum rounds a fraction above 1 - 2^-21 up).  (Checker frequencies outside [0, 2^31), where the sum does not hold
         // ToInt32's parity, make the scene a strict-kernel scene: rt_api.hip.)
         // RT_XY_INDEX: iu, iv = floor(xu), floor(xv) and the boundary mark
-#define RT_XY_INDEX(XU, XV)                                                                                        \
+#define RT_XY_INDEX(XU, XV, FU, FV)                                                                                \
           const unsigned long long su = __builtin_bit_cast(unsigned long long, (XU) + 6442450944.0), sv = __builtin_bit_cast(unsigned long long, (XV) + 6442450944.0);   \
           uint32_t iu = __builtin_amdgcn_alignbit((uint32_t)(su >> 32), (uint32_t)su, 20u) ^ 0x80000000u;       /* floor(x) for x in [0, 2^31) ... */ \
           uint32_t iv = __builtin_amdgcn_alignbit((uint32_t)(sv >> 32), (uint32_t)sv, 20u) ^ 0x80000000u;       \
@@ -869,7 +871,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
             const double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol;                                 \
-            if (!((__builtin_fabs((XU) - __builtin_rint(XU)) >= tol) & (__builtin_fabs((XV) - __builtin_rint(XV)) >= tol))) {   /* NaN: marked */ \
+            /* (a frequency of exactly 0 - stripes - makes the coordinate exactly 0 on every hit: it carries no error and decides nothing) */ \
+            const bool zf = !(K->mark_flags & RT_MARK_ZERO);                                                       \
+            const bool bu = (zf && (FU) == 0.0 && (XU) == 0.0) || (__builtin_fabs((XU) - __builtin_rint(XU)) >= tol);    \
+            const bool bv = (zf && (FV) == 0.0 && (XV) == 0.0) || (__builtin_fabs((XV) - __builtin_rint(XV)) >= tol);    \
+            if (!(bu & bv)) {                                                                                     /* NaN: marked */ \
               uint32_t t3 = threadIdx.x;                                                                          \
               asm volatile("" : "+v"(t3));                                                                        \
               rt_mark_append<SS2>(rt_pixel_of<SS2>(L, t3));                                                        \
@@ -889,7 +895,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           const double xu = u * (double)td.width, xv = v * (double)td.height;
           // max(0, ceil(x) - 1) (main.js:344-345) is floor(x) for every x >= 0 that is not an integer, and the integers are marked:
           // the index comes out of the fixed-point sum (u, v in [0, 1]; widths and heights <= 16384)
-          RT_XY_INDEX(xu, xv)
+          RT_XY_INDEX(xu, xv, 1.0, 1.0)
           const uint32_t xi = min(iu, td.width - 1u), yi = min(iv, td.height - 1u);   // memory safety only; u,v <= 1
 #ifdef RT_AB_HOT_TEXEL
           const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
@@ -904,7 +910,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           const double u = RT_DIV_CONST(t_at, M_PI) / 2.0 + 0.5;   // main.js:127 (its own axes)
           const double v = RT_DIV_CONST(t_as, M_PI / 2.0) / 2.0 + 0.5;  // main.js:128
           const double xu = u * m.c[6], xv = v * m.c[7];
-          RT_XY_INDEX(xu, xv)
+          RT_XY_INDEX(xu, xv, m.c[6], m.c[7])
           const int c = (int)((iu ^ iv) & 1u);                       // the parity of floor(x) = ToInt32(x) & 1 for x in [0, 2^31)
           col[0] = m.c[3 * c]; col[1] = m.c[3 * c + 1]; col[2] = m.c[3 * c + 2];
 #undef RT_XY_INDEX
@@ -1679,6 +1685,40 @@ extern "C" int rt_launch_retrace(const rt_launch *L, int refract, int ss2, unsig
   if (!refract) { if (!ss2) hipLaunchKernelGGL((rt_retrace<false, false>), grid, block, 0, stream, *L); else hipLaunchKernelGGL((rt_retrace<false, true>), grid, block, 0, stream, *L); }
   else          { if (!ss2) hipLaunchKernelGGL((rt_retrace<true, false>), grid, block, 0, stream, *L);  else hipLaunchKernelGGL((rt_retrace<true, true>), grid, block, 0, stream, *L); }
   return (int)hipGetLastError();
+}
+#endif
+
+// Scratch (private segment) bytes per lane of the kernel instantiation the launcher below would pick, from the code object: what the
+// runtime reserves for every wave slot of the device before the first launch (rt_api.hip: scratch_guard).  Returns a hipError_t as int.
+extern "C" int RT_SCRATCH_NAME(int refract, int count, int ss2, int grid_variant, size_t *bytes_per_lane) {
+  const void *f = nullptr;
+#define RT_PICK(R, C, S, G) f = (const void *)&rt_trace<R, C, S, G>
+  if (!RT_STRICT && grid_variant && !count) {
+#if !RT_STRICT
+    if (!refract) { if (!ss2) RT_PICK(false, false, false, true); else RT_PICK(false, false, true, true); }
+    else          { if (!ss2) RT_PICK(true, false, false, true);  else RT_PICK(true, false, true, true); }
+#endif
+  } else if (!count) {
+    if (!refract) { if (!ss2) RT_PICK(false, false, false, false); else RT_PICK(false, false, true, false); }
+    else          { if (!ss2) RT_PICK(true, false, false, false);  else RT_PICK(true, false, true, false); }
+  } else {
+    if (!refract) { if (!ss2) RT_PICK(false, true, false, false); else RT_PICK(false, true, true, false); }
+    else          { if (!ss2) RT_PICK(true, true, false, false);  else RT_PICK(true, true, true, false); }
+  }
+#undef RT_PICK
+  hipFuncAttributes fa;
+  const hipError_t e = hipFuncGetAttributes(&fa, f);
+  if (e == hipSuccess) *bytes_per_lane = (size_t)fa.localSizeBytes;
+  return (int)e;
+}
+#if RT_STRICT
+extern "C" int rt_scratch_retrace(int refract, int ss2, size_t *bytes_per_lane) {
+  const void *f = !refract ? (!ss2 ? (const void *)&rt_retrace<false, false> : (const void *)&rt_retrace<false, true>)
+                           : (!ss2 ? (const void *)&rt_retrace<true, false> : (const void *)&rt_retrace<true, true>);
+  hipFuncAttributes fa;
+  const hipError_t e = hipFuncGetAttributes(&fa, f);
+  if (e == hipSuccess) *bytes_per_lane = (size_t)fa.localSizeBytes;
+  return (int)e;
 }
 #endif
 

@@ -1361,3 +1361,138 @@ def test_the_first_frame_from_a_camera_and_the_later_ones_are_the_same_picture(l
     finally:
         lib.rt_free_device(0, d)
         r.close()
+
+
+# ------------------------------------------------------------------ round 4: mark-list overflow, scratch reservations, frequency limits
+def _striped_scene():
+    """H8 with a floor whose checker has ONE frequency of exactly 0 (stripes): v * 0 == 0 on every hit of that sphere, an exact
+    integer - no error, nothing to decide."""
+    s = rt_host.load_scene("h8")
+    home = next(o for o in s["objects"] if o["mtl"]["sampler"]["kind"] == 2)
+    home["mtl"]["sampler"]["freqU"], home["mtl"]["sampler"]["freqV"] = 10.0, 0.0
+    return rt_host.flatten_scene(s)
+
+
+def test_a_zero_checker_frequency_marks_nothing(lib):
+    """a checker with one frequency equal to 0 gave x = v * 0 = 0 - an exact integer - on every hit of its sphere,
+    every such sample was marked, the list overflowed and the whole 3840x2160 frame was traced again by a two-workgroup launch.  A
+    coordinate whose frequency is 0 carries no error: it is exempt, the frame marks nothing and costs what a frame costs."""
+    blob = _striped_scene()
+    w, h = 3840, 2160
+    rows = [5, 700, 1300, 1700, 2100]
+    r = rt_host.Renderer(blob, 0, lib)
+    d = lib.rt_alloc_device(0, w * h * 4)
+    try:
+        whole = rt_host.RtTiles(h, 0, 1, 1)
+        st = [r.render_tiles(w, h, d, whole, want_stats=True) for _ in range(3)][-1]
+        host = np.empty((h, w, 4), dtype=np.uint8)
+        assert lib.rt_copy_to_host(0, host.ctypes.data, d, w * h * 4) == 0
+    finally:
+        lib.rt_free_device(0, d)
+        r.close()
+    assert st.exact_samples == 0, st.exact_samples
+    assert st.kernel_ms < 1.0, st.kernel_ms                        # (round 3: seconds)
+    want = np.frombuffer(ou.c_oracle_rows(blob, w, h, rows), dtype=np.uint8)
+    assert ou.max_lsb(np.ascontiguousarray(host[rows]).reshape(-1), want)[0] <= 1
+
+
+def test_a_frame_known_to_overflow_the_mark_list_is_rendered_by_the_strict_kernel_once():
+    """A frame that marks more samples than the list holds (test build, RT_TEST_MARK_STRIPES: the zero-frequency coordinate of the
+    striped floor is marked on every hit, as in round 3): the first frame is product launch + rt_retrace over every sample (a real
+    grid now: 256 workgroups, not 2), and from the frame at which the count is known the strict kernel renders the call alone.  The
+    bytes are the strict kernel's every time."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rt_host
+lib = rt_host.load_library(); assert lib.rt_init(1) == 0
+s = rt_host.load_scene("h8")
+home = next(o for o in s["objects"] if o["mtl"]["sampler"]["kind"] == 2)
+home["mtl"]["sampler"]["freqU"], home["mtl"]["sampler"]["freqV"] = 10.0, 0.0
+blob = rt_host.flatten_scene(s); w, h = 960, 540
+r = rt_host.Renderer(blob, 0, lib); d = lib.rt_alloc_device(0, w * h * 4); whole = rt_host.RtTiles(h, 0, 1, 1)
+out = []
+for k in range(4):
+    st = r.render_tiles(w, h, d, whole, want_stats=True)
+    host = C.create_string_buffer(w * h * 4); assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
+    out.append((st.exact_samples, st.kernel_ms, host.raw))
+strict = r.render_tiles(w, h, d, whole, flags=rt_host.RT_FLAG_STRICT_FP, want_stats=True)
+host = C.create_string_buffer(w * h * 4); assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
+print("RESULT", [o[0] for o in out], [round(o[1], 3) for o in out], [o[2] == host.raw for o in out], round(strict.kernel_ms, 3))
+""" % (os.path.join(ou.ROOT, "html5-canvas-raytracer_amd"), os.path.join(ou.ROOT, "tests"))
+    env = dict(os.environ, RT_HIP_LIB=rt_host.TEST_LIB_PATH, RT_TEST_MARK_STRIPES="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
+    exact, ms, same, strict_ms = eval(line[len("RESULT"):])
+    w, h = 960, 540
+    assert exact == [w * h] * 4, exact                       # overflow: every sample of the call came from the strict arithmetic
+    assert all(same), same                                   # ... the strict kernel's bytes, from the first frame on
+    assert ms[-1] < 2.5 * strict_ms + 0.05, (ms, strict_ms)   # known overflow: ONE strict launch, not product + retrace of everything
+
+
+def test_a_scratch_reservation_that_cannot_be_met_is_an_error_not_an_abort():
+    """VERDICT r03 #3.  A kernel with a private segment makes the runtime reserve bytes-per-lane x 64 x wave slots of device memory;
+    when it cannot, the HIP runtime's queue callback aborts the process (profiles/r04_scratch_refusal.log).  Every launch path
+    computes that figure first (from the code object's own private segment size) and returns RT_ERR_NOMEM with the numbers.  Test
+    build: RT_TEST_SCRATCH_PER_LANE pretends the kernels ask for 64 MB per lane (32 TB for the device's wave slots)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rt_host
+lib = rt_host.load_library(); assert lib.rt_init(1) == 0
+w, h = 640, 360
+for name, flags in (("default14", 0), ("h8", rt_host.RT_FLAG_STRICT_FP), ("default14", rt_host.RT_FLAG_STRICT_FP)):
+    r = rt_host.Renderer(rt_host.load_scene(name), 0, lib); d = lib.rt_alloc_device(0, w * h * 4)
+    try:
+        r.render_tiles(w, h, d, rt_host.RtTiles(h, 0, 1, 1), flags=flags, want_stats=True)
+        print("RENDERED", name, flags)
+    except Exception as e:
+        print("REFUSED", name, flags, str(e)[:400].replace("\n", " "))
+    lib.rt_free_device(0, d); r.close()
+# the headline's kernel has no private segment: nothing to reserve, nothing refused
+r = rt_host.Renderer(rt_host.load_scene("h8"), 0, lib); d = lib.rt_alloc_device(0, w * h * 4)
+os.environ.pop("RT_TEST_SCRATCH_PER_LANE")
+st = r.render_tiles(w, h, d, rt_host.RtTiles(h, 0, 1, 1), want_stats=True); print("PLAIN", st.pixels)
+""" % (os.path.join(ou.ROOT, "html5-canvas-raytracer_amd"), os.path.join(ou.ROOT, "tests"))
+    env = dict(os.environ, RT_HIP_LIB=rt_host.TEST_LIB_PATH, RT_TEST_SCRATCH_PER_LANE=str(64 << 20))
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])          # in particular: no abort
+    lines = p.stdout.splitlines()
+    refused = [l for l in lines if l.startswith("REFUSED")]
+    assert len(refused) == 3 and not [l for l in lines if l.startswith("RENDERED")], lines
+    for l in refused:
+        assert "bytes of scratch per lane" in l and "wave slots" in l and "are free" in l, l
+    assert any(l.startswith("PLAIN 230400") for l in lines), lines
+
+
+def test_the_general_kernels_scratch_figure_is_what_the_code_object_says(lib):
+    """The figure the guard works with: per-lane scratch of the kernel the reference's own scene runs (its park stack), read from the
+    loaded code object, equals the resource table's (profiles/kernel_resources.sh; tests/test_kernel_resources.py holds that side)."""
+    fn = lib.rt_scratch_trace_fast
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    b = C.c_size_t(1)
+    assert fn(0, 0, 0, 0, C.byref(b)) == 0 and b.value == 0          # the headline kernel: no private segment at all
+    assert fn(0, 0, 1, 1, C.byref(b)) == 0 and b.value == 0          # cfg5's kernel
+    assert fn(1, 0, 0, 1, C.byref(b)) == 0 and 0 < b.value <= 4096    # the general kernel: the park stack
+
+
+@pytest.mark.parametrize("freq,strict_scene", [(1.0e6, False), (2.0e6, True)])
+def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
+    """the boundary tolerance 2e-13 x frequency must stay well inside the hot path's 2^-20 prefilter.  Up to 2^20 per unit
+    u the product path renders (tolerance <= 2.1e-7, a quarter of the band); beyond, the scene takes the strict kernel."""
+    s = rt_host.load_scene("h8")
+    home = next(o for o in s["objects"] if o["mtl"]["sampler"]["kind"] == 2)
+    home["mtl"]["sampler"]["freqU"], home["mtl"]["sampler"]["freqV"] = freq, freq / 2
+    blob = rt_host.flatten_scene(s)
+    w, h = 480, 270
+    got, st = gpu_tiles(lib, blob, w, h, (h, 0, 1, 1), FAST, stats=True)
+    assert ou.max_lsb(got, ou.c_oracle_render(blob, w, h))[0] <= 1
+    if strict_scene:
+        assert got == gpu_frame(lib, blob, w, h, STRICT)
