@@ -12,7 +12,7 @@ say() { echo "== $TAG $*"; }
 
 step_scratch_probe() {      # what the HIP runtime does when a kernel's scratch reservation cannot be met (once)
   ( ulimit -c 0
-    for args in "8589934592 0" "2147483648 1"; do      # (leave 8 GB free: 4 KB per lane = 2 GB fits) (leave 2 GB free: 32 KB per lane = 16 GB does not)
+    for args in "8589934592 0" "400000000000 1" "2147483648 1"; do      # (leave 8 GB free: 4 KB per lane = 2 GB fits) (hold nothing: 32 KB per lane = 16 GB, memory is there) (leave 2 GB free: it is not)
       echo "---- scratch_refusal_probe $args"
       timeout -k 10 120 build/probe/scratch_refusal_probe $args; echo "exit status $? (134 = SIGABRT, 139 = SIGSEGV, 124 = timeout)"
     done ) > ${O}_scratch_refusal.log 2>&1

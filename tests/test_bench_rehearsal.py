@@ -67,8 +67,10 @@ def test_a_bare_multi_gpu_start_on_a_one_gpu_box_says_what_is_missing():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "RT_BENCH_REHEARSE")}
     r = subprocess.run([sys.executable, os.path.join(ou.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
-    import torch
-    if torch.cuda.device_count() >= 2:
+    # (torch is not imported into THIS process: it brings its own HIP runtime, and a process that has loaded it first hands out IPC
+    # handles the system runtime of a child cannot open - test_ipc_peer_process_renders_into_our_frame runs later in this process)
+    n = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, text=True, env=env).stdout.strip() or 0)
+    if n >= 2:
         pytest.skip("a multi-GPU box: the bare start is a real run here")
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "--gpus 2 but this node shows 1 GPU" in r.stderr
