@@ -1421,7 +1421,7 @@ for k in range(4):
     out.append((st.exact_samples, st.kernel_ms, host.raw))
 strict = r.render_tiles(w, h, d, whole, flags=rt_host.RT_FLAG_STRICT_FP, want_stats=True)
 host = C.create_string_buffer(w * h * 4); assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
-print("RESULT", [o[0] for o in out], [round(o[1], 3) for o in out], [o[2] == host.raw for o in out], round(strict.kernel_ms, 3))
+print("RESULT", repr(([o[0] for o in out], [round(o[1], 3) for o in out], [o[2] == host.raw for o in out], round(strict.kernel_ms, 3))))
 """ % (os.path.join(ou.ROOT, "html5-canvas-raytracer_amd"), os.path.join(ou.ROOT, "tests"))
     env = dict(os.environ, RT_HIP_LIB=rt_host.TEST_LIB_PATH, RT_TEST_MARK_STRIPES="1")
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
