@@ -46,18 +46,33 @@ const scenes = {
   default14_ss3: Object.assign(SC.default14(tex), {supersample: 3}),
   h8_ss4: Object.assign(SC.h8(tex, 3), {supersample: 4}),
 };
-for (const [name, sc] of Object.entries(scenes)) fs.writeFileSync(path.join(SCENES, name + '.json'), F.sceneToJSON(sc, name, SCENES));
+// `node oracle/make_golden.js --only name1,name2`: (re)make just those frames and keep every other entry of the manifest as it is
+// (a full run takes minutes and rewrites the scene files too)
+const onlyArg = process.argv.indexOf('--only');
+const ONLY = onlyArg >= 0 ? new Set(process.argv[onlyArg + 1].split(',')) : null;
+if (!ONLY) for (const [name, sc] of Object.entries(scenes)) fs.writeFileSync(path.join(SCENES, name + '.json'), F.sceneToJSON(sc, name, SCENES));
 
-const manifest = {generator: 'oracle/make_golden.js', reference: 'termuxinator/html5-canvas-raytracer build #741 (main.js)',
+const manifest = ONLY ? JSON.parse(fs.readFileSync(path.join(GOLD, 'manifest.json'), 'utf8')) : {generator: 'oracle/make_golden.js', reference: 'termuxinator/html5-canvas-raytracer build #741 (main.js)',
   node: process.version, v8: process.versions.v8, textures: {earth: sha(tex.earth.texels), mars: sha(tex.mars.texels)},
   frames: [], hashes: []};
 
 function frame(name, scene, w, h, rows, note) {       // store bytes
+  if (ONLY) {
+    if (!ONLY.has(name)) return;
+    manifest.frames = manifest.frames.filter((f) => f.name !== name);
+  }
   const t0 = Date.now();
   const sc = scenes[scene];
   let rgba;
   if (rows === 'main') rgba = H.runMain(w, h);
-  else if ((sc.supersample || 1) > 1) {
+  else if ((sc.supersample || 1) > 1 && Array.isArray(rows)) {
+    // rows of a supersampled frame: the reference renders the k sample rows of each at kw x kh, then the integer box
+    const k = sc.supersample, plain = Object.assign({}, sc, {supersample: 1});
+    rgba = Buffer.concat(rows.map((y) => {
+      const hi = H.renderScene(plain, k * w, k * h, {row0: k * y, row1: k * y + k}).rgba;
+      return Buffer.from(k === 2 ? H.boxFilter2(hi, 2 * w, 2) : H.boxFilter(hi, k * w, k, k));
+    }));
+  } else if ((sc.supersample || 1) > 1) {
     const k = sc.supersample, plain = Object.assign({}, sc, {supersample: 1});
     const hi = H.renderScene(plain, k * w, k * h).rgba;
     rgba = k === 2 ? H.boxFilter2(hi, 2 * w, 2 * h) : H.boxFilter(hi, k * w, k * h, k);
@@ -72,6 +87,7 @@ function frame(name, scene, w, h, rows, note) {       // store bytes
   console.log(name, sha(rgba).slice(0, 16), (Date.now() - t0) + 'ms');
 }
 function hashOnly(name, scene, w, h, viaMain) {       // store only the SHA-256
+  if (ONLY) return;
   const t0 = Date.now();
   const rgba = viaMain ? H.runMain(w, h) : H.renderScene(scenes[scene], w, h).rgba;
   manifest.hashes.push({name, scene, w, h, via: viaMain ? 'main()' : 'intersectWorld', sha256: sha(rgba)});
@@ -99,13 +115,17 @@ frame('lcg64_ss3_96x64', 'lcg64_ss3', 96, 64, null, 'SURVEY 8(f)-4: reference at
 frame('lcg64_ss4_96x64', 'lcg64_ss4', 96, 64, null, 'SURVEY 8(f)-4: reference at 384x256 then (sum+8)>>4 per channel');
 frame('default14_ss3_67x45', 'default14_ss3', 67, 45, null, 'odd sample grid (201x135): centre row and column of the SAMPLES; refraction');
 frame('h8_ss4_131x60', 'h8_ss4', 131, 60, null, 'ragged width, 4x4 box');
+// round 4: the reference's own scene at the headline's size (bench.py's `reference_scene` leg checks its frame against these rows),
+// and BASELINE configs[4] at FULL size: rows of the 16384x16384 frame, each two sample rows of the 32768x32768 grid through intersectWorld
+frame('default14_3840x2160_rows', 'default14', 3840, 2160, [150, 700, 1000, 1150, 1300, 1500, 1800, 2100], 'the reference scene at the headline size, sampled rows (an even grid: no centre row)');
+frame('lcg64_16384x16384_rows', 'lcg64', 16384, 16384, [40, 6000, 8100, 9000, 10500, 13000], 'BASELINE configs[4] at full size, sampled rows: reference at 32768x32768 then (a+b+c+d+2)>>2');
 // hashes of larger frames
 hashOnly('default14_main_256x256', 'default14', 256, 256, true);
 hashOnly('default14_main_640x360', 'default14', 640, 360, true);
 hashOnly('h8_960x540', 'h8', 960, 540, false);
 hashOnly('h8_d8_960x540', 'h8_d8', 960, 540, false);
 hashOnly('cfg2_1920x1080', 'cfg2', 1920, 1080, false);
-if (process.argv.includes('--full4k')) hashOnly('h8_3840x2160', 'h8', 3840, 2160, false);
+if (ONLY) { /* hashes stay */ } else if (process.argv.includes('--full4k')) hashOnly('h8_3840x2160', 'h8', 3840, 2160, false);
 else manifest.hashes.push({name: 'h8_3840x2160', scene: 'h8', w: 3840, h: 2160, via: 'intersectWorld', sha256: '1d4235fa69b729e4e622e14a92fbb5c8ea6f881220d77b4cd196a57f17e43595', note: 'SURVEY §8(c) probe; re-derived with --full4k'});
 
 fs.writeFileSync(path.join(GOLD, 'manifest.json'), JSON.stringify(manifest, null, 1));

@@ -86,11 +86,13 @@ function withPinnedRandom(fn) {
   try { return fn(); } finally { Math.random = saved; }
 }
 
-// The reference's own frame (main.js:77-214) at w x h.
-function runMain(w, h) {
+// The reference's own frame (main.js:77-214) at w x h.  opts.realRandom: leave Math.random alone - the stars of main.js:135-139 as
+// the reference draws them, different on every run (oracle/make_stars_fixture.js takes their statistics; nothing is compared pixel for pixel).
+function runMain(w, h, opts) {
   const L = loadReference();
   L.state.width = w; L.state.height = h;
-  return withPinnedRandom(() => { L.ref.main(); L.drain(); return new Uint8Array(L.state.frame.data.buffer); });
+  const go = () => { L.ref.main(); L.drain(); return new Uint8Array(L.state.frame.data.buffer); };
+  return (opts && opts.realRandom) ? go() : withPinnedRandom(go);
 }
 
 // Build reference-side objects for one of OUR scenes; samplers are closures over the

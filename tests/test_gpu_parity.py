@@ -768,6 +768,17 @@ def test_hashed_stars_sampler(lib):
         assert ou.max_lsb(gpu_frame(lib, b, 200, 120), ou.c_oracle_render(b, 200, 120))[0] <= 1, name
 
 
+def test_hashed_stars_match_the_references_statistics(lib):
+    """The kernel's stars (kind 3) against the statistics of the reference's own random stars (tests/golden/stars_statistics.json:
+    24 runs of main() with its real Math.random): density within 4 sigma of the reference's pooled rate, grey levels distributed
+    as the reference's, nothing but black and grey in the sky, the picture below the horizon changed only where it mirrors the sky."""
+    for w, h in ((1920, 1080), (640, 360)):
+        stars = gpu_frame(lib, rt_host.flatten_scene(rt_host.load_scene("default14_stars")), w, h)
+        black = gpu_frame(lib, rt_host.flatten_scene(rt_host.load_scene("default14")), w, h)
+        got = ou.stars_statistics_check(stars, black, w, h)
+        assert got["stars"] > 20, got
+
+
 @pytest.mark.skipif(ou.node_path() is None, reason="node not installed")
 @pytest.mark.parametrize("scene,w,h", [("cfg2", 1920, 1080), ("h8", 3840, 2160)])
 def test_full_size_frame_vs_bit_exact_js_restatement(lib, scene, w, h, tmp_path):

