@@ -97,7 +97,7 @@ def cpu_baseline(scene_name, w, h):
             "host_cpus": os.cpu_count()}
 
 
-def pmc_passes(argv, kernel_substr="rt_trace"):
+def pmc_passes(argv, kernel_substr="rt_trace", only_traffic=False):
     """rocprofv3 counter passes over a short CHILD run of this same command (N=1): HBM bytes per launch (WRITE_SIZE, FETCH_SIZE in
     separate passes - they do not fit one - with the guide's gfx950 correction: FETCH_SIZE counts half the bytes) and the FP64
     VALU instruction counters.  Returns (dict, note); every failure is reported in the note and leaves the values None."""
@@ -110,6 +110,8 @@ def pmc_passes(argv, kernel_substr="rt_trace"):
     passes = [("WRITE_SIZE",), ("FETCH_SIZE",), ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU", "SQ_INSTS_SALU"),
               ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY")]     # issue cycles (optional: a failure of this pass voids nothing else)
     optional = {"SQ_BUSY_CYCLES"}
+    if only_traffic:
+        passes = passes[:2]
     env = dict(os.environ, TMPDIR="/tmp", RT_BENCH_CHILD="1", RT_BENCH_NO_SETTLE="1")     # counters do not depend on clocks: no need to settle them
     for counters in passes:
         d = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
@@ -195,6 +197,62 @@ def moving_camera(scene, k, n):
     a0 = math.atan2(o[0], o[2])
     a = a0 + 0.35 * math.sin(2.0 * math.pi * (k + 0.37) / n) + 0.02
     return look_at([r * math.sin(a), o[1] + 0.3 * math.cos(2.0 * math.pi * k / n) + 0.05, r * math.cos(a)], [0.1, 1.5, 0.0])
+
+
+def reference_scene_leg(args, w, h, lib, dev_index, stream, torch, np):
+    """The scene the reference's own main() draws (main.js:107-163: 14 spheres, glass and a sphere that both reflects and refracts, depth 8,
+    main.js:194; Math.random pinned, so the sky is black) at the headline's frame size: the general kernel (rt_trace<REFRACT=1>) on one
+    GPU, frames in HBM, launches back to back - kernel time by HIP events on the launch stream, HBM traffic from the same PMC passes as
+    the headline's (a child run with --scene default14), parity against rows the reference itself rendered."""
+    import rt_host
+    import oracle_util as ou
+    name = "default14"
+    scene = rt_host.load_scene(name)
+    out = {"scene": "%s: %d spheres, %d lights, depth %d (the reference's own scene, main.js:107-163, :194)" % (name, len(scene["objects"]), len(scene["lights"]), scene["segs"]),
+           "w": w, "h": h}
+    r = rt_host.Renderer(scene, dev_index, lib)
+    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=torch.device("cuda", dev_index))
+    whole = rt_host.RtTiles(h, 0, 1, 1)
+    for _ in range(30):
+        r.render_tiles(w, h, frame.data_ptr(), whole, stream=stream)
+    torch.cuda.synchronize()
+    n = 200
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev_a.record()
+    for _ in range(n):
+        r.render_tiles(w, h, frame.data_ptr(), whole, stream=stream)
+    ev_b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev_a.elapsed_time(ev_b) / n
+    out.update(kernel_ms=round(kernel_ms, 4), ms_per_step=round(wall / n * 1e3, 4), value=round(w * h * n / wall / 1e6, 2), unit="Mpixel/s", steps=n)
+    entry = next((f for f in ou.manifest()["frames"] if f["scene"] == name and (f["w"], f["h"]) == (w, h) and f["rows"]), None)
+    host = frame.cpu().numpy()
+    if entry:
+        out["max_lsb_vs_reference_rows"] = int(ou.max_lsb(np.ascontiguousarray(host[entry["rows"]]).reshape(-1), ou.golden_frame(entry))[0])
+        out["parity_checked_against"] = "tests/golden/%s (rendered by the reference itself)" % entry["file"]
+    else:
+        rows = sorted(set(int((k + 0.5) * h / 5) for k in range(5)))
+        want = np.frombuffer(ou.c_oracle_rows(rt_host.flatten_scene(scene), w, h, rows), dtype=np.uint8)
+        out["max_lsb_vs_reference_rows"] = int(ou.max_lsb(np.ascontiguousarray(host[rows]).reshape(-1), want)[0])
+        out["parity_checked_against"] = "oracle/rt_oracle.c rows %s" % rows
+    out["parity_ok"] = out["max_lsb_vs_reference_rows"] <= 1
+    r.close()
+    algo = 4.0 * w * h
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "algorithmic_bytes_per_launch": algo, "kernel": "rt_trace<REFRACT=1>"}
+    if not args.no_pmc and os.environ.get("RT_BENCH_CHILD") != "1":
+        pmc, note = pmc_passes(["--scene", name, "--width", str(w), "--height", str(h)], only_traffic=True)
+        if pmc:
+            roof["traffic"] = pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / algo, 3)
+            roof["traffic_source"] = "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) over a 12-step child run with --scene %s; FETCH_SIZE doubled (gfx950)" % name
+        else:
+            roof["traffic_source"] = "not collected: %s" % note
+    out["roofline"] = roof
+    return out
 
 
 def cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, steps):
@@ -963,6 +1021,11 @@ def main():
                     out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(64, min(args.steps, 512))))
                 except Exception as e:   # noqa: BLE001  (the headline must still be reported)
                     out["cold_frame"] = {"note": "failed: %r" % (e,)}
+            if world == 1 and not args.no_cold and not args.strict_fp and args.config == "cfg3" and not args.scene and os.environ.get("RT_BENCH_CHILD") != "1":
+                try:
+                    out["reference_scene"] = reference_scene_leg(args, w, h, lib, dev_index, stream, torch, np)
+                except Exception as e:   # noqa: BLE001  (the headline must still be reported)
+                    out["reference_scene"] = {"note": "failed: %r" % (e,)}
             if world == 1 and not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline(scene_name, w, h)
@@ -1000,6 +1063,9 @@ def main():
                 if k in out_b["config"]:
                     out["batch_mode"][k] = out_b["config"][k]
     if rank == 0:
+        ref_leg = out.get("reference_scene") or {}
+        if ref_leg.get("parity_ok") is False:
+            parity_ok, max_lsb = False, max(max_lsb, ref_leg["max_lsb_vs_reference_rows"])
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if multi:
