@@ -1297,7 +1297,26 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane))) return rc;
       if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
     }
+#ifdef RT_WAVE_LOG
+    // measurement build: RT_WAVE_LOG_FILE=<path> - every wave's entry / exit time and place of THIS launch, written after it has finished
+    unsigned long long *d_wave_log = nullptr;
+    const size_t wave_log_words = (size_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u) * 4u;
+    if (getenv("RT_WAVE_LOG_FILE")) {
+      if (hipMalloc((void **)&d_wave_log, wave_log_words * 8u) == hipSuccess) (void)hipMemsetAsync(d_wave_log, 0, wave_log_words * 8u, stream);
+      L.wave_log = d_wave_log;
+    }
+#endif
     err = rt_launch_trace_fast(&L, s->refract, count, ss2, lds_for(false), stream);
+#ifdef RT_WAVE_LOG
+    if (d_wave_log) {
+      std::vector<unsigned long long> hostlog(wave_log_words);
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(hostlog.data(), d_wave_log, wave_log_words * 8u, hipMemcpyDeviceToHost);
+      (void)hipFree(d_wave_log);
+      if (FILE *fp = fopen(getenv("RT_WAVE_LOG_FILE"), "wb")) { fwrite(hostlog.data(), 8u, wave_log_words, fp); fclose(fp); }
+      L.wave_log = nullptr;
+    }
+#endif
     // Centre row / centre column of a sample grid with an ODD number of rows / columns (supersample 2 makes it even).  The primary
     // rays there have a direction component that is EXACTLY zero (main.js:186: x - w/2 + 0.5 == 0), so they - and every ray they
     // spawn that stays in that plane - live in a coordinate plane through the camera, and a sphere centred on that plane (the

@@ -110,6 +110,11 @@ struct rt_launch {
   uint32_t known_tag;                // (the camera generation the frame is rendered with)
   uint32_t centre_row, centre_col;   // frame row / column of the odd sample grid's centre within this call's tiles, or ~0u
   uint32_t retrace_all;              // test build (RT_EXACT_ALL): every sample of the call
+#ifdef RT_WAVE_LOG
+  // measurement builds only (profiles/ab_build.sh ... "-DRT_WAVE_LOG" hybrid; profiles/wave_timeline.py): per wave of the product launch
+  // four words {s_memrealtime at entry, at exit, HW_ID | XCC_ID << 32, workgroup}; NULL = off
+  unsigned long long *wave_log;
+#endif
 #ifdef RT_TESTING
   // test build only (librt_hip_test.so): per-node records of ONE sample's ray tree, for parity debugging
   double *probe;                     // RT_PROBE_NODES records of RT_PROBE_WORDS doubles, or NULL

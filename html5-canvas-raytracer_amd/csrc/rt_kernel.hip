@@ -1375,6 +1375,15 @@ template <bool REFRACT, bool COUNT, bool SS2, bool GRID>
 // waves spills into its loops: -9 %).
 __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_PER_EU : (RT_WAVES_PER_EU > 5 ? RT_WAVES_PER_EU : 5))) rt_trace(const rt_launch L) {
   extern __shared__ double lds_raw[];
+#if defined(RT_WAVE_LOG) && !RT_STRICT
+  // measurement build: when this wave started, and where (nothing is kept in registers: the exit stamp recomputes its slot)
+  if (unsigned long long *const wl = rt_cold_args()->wave_log; wl != nullptr && (threadIdx.x & 63u) == 0u) {
+    unsigned long long *q = wl + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (RT_WG_THREADS / 64u) + (threadIdx.x >> 6)) * 4u;
+    q[0] = __builtin_amdgcn_s_memrealtime();
+    q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4u) | (0u << 6) | (31u << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20u) | (0u << 6) | (31u << 11)) << 32);
+    q[3] = blockIdx.x;
+  }
+#endif
   // ---- stage the per-workgroup tables into LDS: ONE contiguous image in HBM (materials | texture descriptors |
   //      cull rectangles, laid out exactly as the LDS copy), so a workgroup pays one memory latency, not three;
   //      the loads are issued first and land while the ray is being generated ----
@@ -1583,6 +1592,10 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     }
   }
 
+#if defined(RT_WAVE_LOG) && !RT_STRICT
+  if (unsigned long long *const wl = rt_cold_args()->wave_log; wl != nullptr && (tid2 & 63u) == 0u)
+    wl[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (RT_WG_THREADS / 64u) + (tid2 >> 6)) * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (COUNT) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
