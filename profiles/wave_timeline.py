@@ -88,5 +88,37 @@ print("resident waves every 10 us (all / deep): " + " ".join("%d/%d" % x for x i
 order = np.argsort(wg, kind="stable")
 first = order[: len(order) // 20]
 print("the first 5 %% of the launch table's workgroups: start median %.1f us, duration median %.1f us" % (np.median(start[first]), np.median(dur[first])))
+# where in the picture the long waves are, and which of them started late: the launch table (host build = the GPU's, word for word)
+# gives every workgroup its block
+if "--map" in sys.argv:
+    import ctypes as C
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    buf = C.create_string_buffer(blob, len(blob))
+    t = rt_host.RtTiles(h, 0, 1, 1)
+    n, nb = C.c_uint32(), C.c_uint32()
+    flags = int(sys.argv[sys.argv.index("--table-flags") + 1]) if "--table-flags" in sys.argv else 7
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), flags, None, C.byref(n), C.byref(nb)) == 0
+    n8 = (nb.value + 7) // 8
+    ent = (C.c_uint32 * (32 * n8))()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), flags, ent, C.byref(n), C.byref(nb)) == 0
+    ent = np.frombuffer(ent, dtype=np.uint32).reshape(-1, 4)
+    slot = (wg % 8) * n8 + wg // 8
+    e0 = ent[slot, 0]
+    tx, fr = (e0 & 2047).astype(np.int64), (e0 >> 15).astype(np.int64)
+    ss = rt_host.load_scene(scene).get("supersample", 1)
+    cw, ch = 96, 72                                   # pixels per map cell
+    gx, gy = (w + cw - 1) // cw, (h + ch - 1) // ch
+    mx = np.zeros((gy, gx)); late = np.zeros((gy, gx))
+    cx, cy = np.minimum(tx * 32 // cw, gx - 1), np.minimum(fr // ch, gy - 1)
+    np.maximum.at(mx, (cy, cx), dur)
+    np.maximum.at(late, (cy, cx), np.where(deep, start, 0.0))
+    print("longest wave per %dx%d-pixel cell, in units of 20 us (. = below 20 us):" % (cw, ch))
+    for row in mx:
+        print("".join("." if v < 20 else "%x" % min(15, int(v // 20)) for v in row))
+    print("latest START of a deep wave per cell, in units of 20 us (. = no deep wave, 0 = started within 20 us):")
+    for y in range(gy):
+        print("".join("." if mx[y, x] < deep_us else "%x" % min(15, int(late[y, x] // 20)) for x in range(gx)))
+    worst = np.argsort(-end)[:12]
+    print("the 12 waves that ended last: " + "; ".join("tile_x %d row %d start %.0f dur %.0f rank %d" % (tx[i], fr[i], start[i], dur[i], wg[i]) for i in worst))
 r.close()
 lib.rt_free_device(0, d)
