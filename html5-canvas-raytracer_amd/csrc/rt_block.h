@@ -19,8 +19,8 @@
 //                  beyond the patch.  The union over the block's candidates, per light, is a 16-bit set of loop-order sphere
 //                  indices (0xffffffff = no statement: scan everything); with more than 16 loop spheres a light's set is stored
 //                  as empty (0) or not (0xffff);
-//   * cost       - 1 + the weights of the spheres whose screen rectangle (the primary-ray cull's) touches the block: what ranks
-//                  the blocks dearest first.
+//   * cost       - 1 + the weights of the spheres whose screen rectangle (the primary-ray cull's) touches the block, + what its
+//                  mirrors show of the scene's dearest spheres (rt_bounce_cost): what ranks the blocks dearest first.
 #ifndef RT_BLOCK_H
 #define RT_BLOCK_H
 
@@ -41,6 +41,7 @@
 #define RT_TABLE_GEOMETRY 32u    /* the camera is usable for the cone test (finite, non-zero axis sums, positive projection distance) */
 #define RT_TABLE_NO_SKY 64u      /* RT_FLAG_NO_SKY: the table holds no entry for sky blocks (their slots stay zero: no workgroup renders them) */
 #define RT_TABLE_SKY_ONLY 128u   /* RT_FLAG_SKY_ONLY: the table holds ONLY the sky runs */
+#define RT_TABLE_BOUNCE 256u     /* ranked launch of a scene with a sphere that both reflects and refracts: a block's cost also counts such spheres seen in its mirrors */
 #define RT_SKY_RUN_MAX 32u       /* consecutive sky blocks of a row block that share ONE entry */
 #define RT_COST_MAX 1023u        /* costs are clamped here (the ranking only has to order the blocks roughly) */
 
@@ -57,6 +58,8 @@ struct rt_ball {
   uint32_t always[2];
   uint32_t loop;                 // index in the product kernel's loop order (enclosing sphere last)
   uint32_t everywhere;           // the camera is inside / on / too near: no statement about any block
+  uint32_t bounce;               // cost ranking only (RT_TABLE_BOUNCE): bit 0 the sphere reflects, bit 1 it refracts (depth >= 3)
+  uint32_t heavy;                // ... and its weight if it does BOTH (every hit a two-child node of the ray tree, main.js:268-278), else 0
 };
 
 // a sphere's screen rectangle on the workgroup grid and what a block that shows it is expected to cost
@@ -132,6 +135,47 @@ RT_HD inline rt_cone rt_block_cone(const rt_table_params &P, uint32_t x, uint32_
   return K;
 }
 
+// Cost ranking only: what a block's MIRRORS add to its cost.  The scene's dearest pixels are the hits on a sphere that both reflects and
+// refracts (a binary ray tree: up to 31 nodes at depth 8) - and, after them, the pixels of OTHER spheres in which such a sphere is
+// mirrored (measured, profiles/r04_ab_log.md: in the reference's own scene those blocks' waves ran 100-150 us, were ranked with the
+// ordinary mirrors, started 100-140 us into a 200 us launch and WERE its last 70 us).  For candidate sphere ci of the block that
+// reflects (or refracts): where the cone's axis meets it, the mirrored (or straight-through) direction there, a spread - the cone's
+// half-angle magnified by the curvature, everything when the axis only grazes the sphere - and for every heavy sphere j the same
+// angle test as everywhere else in this file.  A hit adds half of j's weight.  An estimate that only RANKS: no margin is owed,
+// but host and device must compute the same number (plain binary64, no contraction, IEEE sqrt and division).
+RT_HD inline uint32_t rt_bounce_cost(const rt_table_params &P, const rt_cone &K, const rt_ball *balls, uint32_t ci) {
+  const rt_ball &B = balls[ci];
+  if (!B.bounce || B.everywhere) return 0u;
+  const double *ax = K.ax;
+  const double cs = ax[0] * B.c[0] + ax[1] * B.c[1] + ax[2] * B.c[2], c = B.len * cs, disc = c * c - B.k;
+  const bool graze = !(B.k > 0.0) || !(disc > 0.0);
+  const double t = graze ? B.tangent : c - sqrt(disc);
+  const double Q[3] = {P.cam[0] + t * ax[0], P.cam[1] + t * ax[1], P.cam[2] + t * ax[2]};
+  double n[3] = {Q[0] - B.o[0], Q[1] - B.o[1], Q[2] - B.o[2]};
+  const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (!(nl > 0.0)) return 0u;
+  n[0] /= nl; n[1] /= nl; n[2] /= nl;
+  const double cosi = -(ax[0] * n[0] + ax[1] * n[1] + ax[2] * n[2]);
+  const bool wide = graze || !(cosi > 0.1);
+  const double s_sig = wide ? 1.0 : fmin(1.0, K.sin_a * (1.0 + 2.0 * t / (B.R * cosi)) * 1.5 + 0.02), c_sig = sqrt(1.0 - s_sig * s_sig);
+  const double s_thr = fmin(1.0, s_sig + 0.5), c_thr = sqrt(1.0 - s_thr * s_thr);          // straight through a refracting sphere: bent by up to ~30 degrees
+  const double dr[3] = {ax[0] + 2.0 * cosi * n[0], ax[1] + 2.0 * cosi * n[1], ax[2] + 2.0 * cosi * n[2]};
+  uint32_t extra = 0u;
+  for (uint32_t j = 0; j < P.n_balls; j++) {
+    const rt_ball &H = balls[j];
+    if (!H.heavy || j == ci) continue;
+    const double W[3] = {H.o[0] - Q[0], H.o[1] - Q[1], H.o[2] - Q[2]};
+    const double wl = sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+    if (!(wl > 0.0)) continue;
+    const double sb = fmin(1.0, H.R / wl), cb = sqrt(1.0 - sb * sb);
+    bool sees = false;
+    if (B.bounce & 1u) sees = (dr[0] * W[0] + dr[1] * W[1] + dr[2] * W[2]) >= (c_sig * cb - s_sig * sb) * wl;
+    if (!sees && (B.bounce & 2u)) sees = (ax[0] * W[0] + ax[1] * W[1] + ax[2] * W[2]) >= (c_thr * cb - s_thr * sb) * wl;
+    if (sees) extra += H.heavy / 2u;
+  }
+  return extra;
+}
+
 // can some ray of the cone meet sphere B?  0: no; 1: yes (or NaN: touched); 2: the camera is inside / on / too near B - no statement
 // about any block
 RT_HD inline uint32_t rt_ball_touch(const rt_cone &K, const rt_ball &B) {
@@ -194,8 +238,9 @@ RT_HD inline bool rt_cand_masks(const rt_table_params &P, const rt_cone &K, cons
 }
 
 // touched / candidates / shadow masks of block (x, y), one block after the other (the host); *touched = 1 also when nothing can be said
-RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *balls, uint32_t x, uint32_t y, uint32_t *touched, uint32_t *cands_out, uint32_t *smask_out) {
-  *touched = 1u; *cands_out = 0u; *smask_out = 0xffffffffu;
+RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *balls, uint32_t x, uint32_t y, uint32_t *touched, uint32_t *cands_out, uint32_t *smask_out,
+                                     uint32_t *bounce_extra) {
+  *touched = 1u; *cands_out = 0u; *smask_out = 0xffffffffu; *bounce_extra = 0u;
   const rt_cone K = rt_block_cone(P, x, y);
   bool hit = K.hit != 0u, doubt = K.doubt != 0u;
   if (!(P.flags & RT_TABLE_GEOMETRY)) return;
@@ -210,6 +255,8 @@ RT_HD inline void rt_block_statement(const rt_table_params &P, const rt_ball *ba
   *touched = hit ? 1u : 0u;
   if (doubt || n_cand == 0u) return;
   *cands_out = rt_cand_word(P, balls, cand, n_cand);
+  if (P.flags & RT_TABLE_BOUNCE)
+    for (uint32_t ci = 0; ci < P.n_balls; ci++) if (cand[ci >> 6] >> (ci & 63u) & 1ull) *bounce_extra += rt_bounce_cost(P, K, balls, ci);
   if (!(P.flags & RT_TABLE_MASKS)) return;
   uint32_t mk[2] = {0u, 0u};
   for (uint32_t ci = 0; ci < P.n_balls; ci++) {

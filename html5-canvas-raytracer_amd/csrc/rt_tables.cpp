@@ -266,10 +266,15 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
   const uint32_t n_loop = hd->n_objects - (sky_sphere != ~0u ? 1u : 0u);
   const bool want_masks = shadow_masks && n_loop <= 256u && hd->n_lights >= 1u && hd->n_lights <= 2u && lights != nullptr;
   const bool want_cands = name_candidates && n_loop <= 256u;                 // (no light needed, and any enclosing sphere: it is outside the loops)
+  // (ranking) blocks whose mirrors show a sphere that both reflects and refracts are nearly as dear as that sphere's own: rt_block.h, rt_bounce_cost
+  bool want_bounce = false;
+  if (table_is_ranked(ranked, n64) && hd->segs >= 3u)
+    for (uint32_t j = 0; j < hd->n_objects; j++) if (j != sky_sphere && ob[j].albedo[3] > 0.0 && ob[j].albedo[4] > 0.0 && weight[j] >= 16u) want_bounce = true;
   const bool geometry = std::isfinite(P->as0) && std::isfinite(P->as1) && std::isfinite(P->as2) && P->as0 != 0.0 && P->as1 != 0.0 && P->as2 != 0.0 &&
                         std::isfinite(proj_d) && proj_d > 0.0;
   P->flags = (mark_sky ? RT_TABLE_SKY : 0u) | (want_masks ? RT_TABLE_MASKS : 0u) | (want_cands ? RT_TABLE_CANDS : 0u) | (n_loop > 16u ? RT_TABLE_WIDE : 0u) |
-             (table_is_ranked(ranked, n64) ? RT_TABLE_RANK : 0u) | ((geometry && (mark_sky || want_masks || want_cands)) ? RT_TABLE_GEOMETRY : 0u);
+             (table_is_ranked(ranked, n64) ? RT_TABLE_RANK : 0u) | ((geometry && (mark_sky || want_masks || want_cands || want_bounce)) ? RT_TABLE_GEOMETRY : 0u) |
+             ((geometry && want_bounce) ? RT_TABLE_BOUNCE : 0u);
   P->cost_bins = 1u;
   P->n_lights = want_masks ? hd->n_lights : 0u;
   for (uint32_t k = 0; k < P->n_lights; k++) for (int c = 0; c < 3; c++) P->lights[k][c] = lights[k][c];
@@ -287,6 +292,10 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
       B.everywhere = (!(ob[j].r2 > 0.0) || !std::isfinite(B.len) || !std::isfinite(B.R) || !(B.len > B.R * (1.0 + 1e-7))) ? 1u : 0u;      // camera inside / on / unknown
       if (!B.everywhere) { for (int c = 0; c < 3; c++) B.c[c] /= B.len; B.sin_b = B.R / B.len; B.cos_b = sqrt(1.0 - B.sin_b * B.sin_b); }
       B.tangent = sqrt(fmax(B.k, 0.0));
+      if (P->flags & RT_TABLE_BOUNCE) {
+        B.bounce = (ob[j].albedo[3] > 0.0 ? 1u : 0u) | (ob[j].albedo[4] > 0.0 ? 2u : 0u);
+        B.heavy = (B.bounce == 3u && weight[j] >= 16u) ? weight[j] : 0u;
+      }
       for (uint32_t k = 0; k < P->n_lights; k++) {      // the sphere as an occluder seen from light k
         for (int c = 0; c < 3; c++) B.lw[k][c] = B.o[c] - lights[k][c];
         B.wl[k] = sqrt(B.lw[k][0] * B.lw[k][0] + B.lw[k][1] * B.lw[k][1] + B.lw[k][2] * B.lw[k][2]);
@@ -321,6 +330,11 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
   if (P->flags & RT_TABLE_RANK) {
     uint64_t bound = 1u;
     for (const rt_cost_rect &q : *rects) bound += q.weight;
+    if (P->flags & RT_TABLE_BOUNCE) {                   // every mirror of a block may show every heavy sphere
+      uint64_t heavy = 0u, mirrors = 0u;
+      for (const rt_ball &B : *balls) { heavy += B.heavy / 2u; mirrors += B.bounce ? 1u : 0u; }
+      bound += heavy * mirrors;
+    }
     P->cost_bins = (uint32_t)(bound < RT_COST_MAX ? bound : RT_COST_MAX);
     if ((uint64_t)P->cost_bins * ny > (8u << 20)) { P->flags &= ~RT_TABLE_RANK; P->cost_bins = 1u; rects->clear(); P->n_rects = 0u; }
   }
@@ -345,8 +359,9 @@ std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sph
   for (uint32_t y = 0; y < ny; y++)
     for (uint32_t x = 0; x < tiles_x; x++) {
       const size_t at = (size_t)y * tiles_x + x;
-      rt_block_statement(P, balls.data(), x, y, &touched[at], &cands[at], &smask[at]);
-      if (rank) cost[at] = rt_block_cost(P, rects.data(), x, y);
+      uint32_t extra = 0u;
+      rt_block_statement(P, balls.data(), x, y, &touched[at], &cands[at], &smask[at], &extra);
+      if (rank) { const uint32_t c = rt_block_cost(P, rects.data(), x, y) + extra; cost[at] = c < RT_COST_MAX ? c : RT_COST_MAX; }
     }
   // The entries: one per workgroup.  A block that shows a sphere is an entry of its own; consecutive sky blocks of one row
   // block are ONE entry (a run of up to RT_SKY_RUN_MAX blocks: its workgroup stores the constant into each).

@@ -39,6 +39,12 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return v;
 }
 template <uint32_t SUB>
+__device__ __forceinline__ uint32_t group_add(uint32_t v) {
+#pragma unroll
+  for (uint32_t d = 1; d < SUB; d <<= 1) v += (uint32_t)__shfl_xor((int)v, (int)d);
+  return v;
+}
+template <uint32_t SUB>
 __device__ __forceinline__ uint64_t group_or64(uint64_t v) { return (uint64_t)group_or<SUB>((uint32_t)v) | ((uint64_t)group_or<SUB>((uint32_t)(v >> 32)) << 32); }
 
 // The parameters, the cone-test spheres and the cost rectangles are staged in LDS first - one coalesced load per work-item - and
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
   for (uint32_t c = threadIdx.x; c < bins; c += WG_ROWS) l_hist[c] = 0u;
   const uint32_t sub = threadIdx.x % SUB;
   for (uint32_t x = threadIdx.x / SUB; x < tiles_x; x += WG_ROWS / SUB) {
-    uint32_t touched = 1u, cands = 0u, smask = 0xffffffffu;
+    uint32_t touched = 1u, cands = 0u, smask = 0xffffffffu, extra = 0u;
 #ifndef RT_TAB_NO_STMT   /* (defined: timing experiments, profiles/ab_build.sh) */
     if (P.flags & RT_TABLE_GEOMETRY) {
       const rt_cone K = rt_block_cone(P, x, y);
@@ -101,6 +107,10 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
       touched = (K.hit || everywhere || n_cand) ? 1u : 0u;
       if (!doubt && n_cand) {
         if (sub == 0u) cands = rt_cand_word(P, balls, cand, n_cand);
+        if (P.flags & RT_TABLE_BOUNCE) {                // (ranking only) what the block's mirrors show of the scene's dearest spheres
+          for (uint32_t ci = sub; ci < P.n_balls; ci += SUB) if ((cand[ci >> 6] >> (ci & 63u)) & 1ull) extra += rt_bounce_cost(P, K, balls, ci);
+          extra = group_add<SUB>(extra);
+        }
         if (P.flags & RT_TABLE_MASKS) {
           uint32_t mk[2] = {0u, 0u}, none = 0u;
           for (uint32_t ci = sub; ci < P.n_balls; ci += SUB)
@@ -119,7 +129,8 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
 #ifdef RT_TAB_NO_COST
     const uint32_t cost = 1u + (x & 3u);
 #else
-    const uint32_t cost = rank ? rt_block_cost(P, rects, x, y) : 1u;
+    uint32_t cost = rank ? rt_block_cost(P, rects, x, y) + extra : 1u;
+    cost = cost < RT_COST_MAX ? cost : RT_COST_MAX;
 #endif
     const size_t at = (size_t)y * tiles_x + x;
     T.blk[3u * at] = cost; T.blk[3u * at + 1u] = smask; T.blk[3u * at + 2u] = cands;
