@@ -184,8 +184,12 @@ struct rt_scene_dev {
   rt_sphere *d_objects_b;        // object records with the enclosing sphere moved last (ordering B); NULL if none
   uint64_t *d_shadow_grid;       // light grids for the product kernel's loop order, or NULL (few spheres)
   uint64_t *d_bounce_table;      // bounce table for the same order, or NULL (few spheres, or depth < 2)
-  uint8_t *d_lds_image;          // per ordering: [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)], the LDS image (in the camera block when it holds the rectangles)
-  uint8_t *d_cam;                // the camera block: per ordering [anchored at the camera N | cull rectangles N], then the LDS images when they hold the rectangles
+  uint8_t *d_lds_image;          // many spheres: per ordering [materials (rt_mtl) | 16 texture descriptors], the LDS image (few spheres: it holds the cull rectangles and lives in the camera block)
+  // The camera block: per ordering [anchored at the camera N | cull rectangles N], then (few spheres) the LDS images.  TWO of them:
+  // camera generation g lives in block g & 1, so that the block of the NEXT camera can be written - on the scene's own side stream,
+  // by rt_scene_set_camera - while launches with the current one are still running.
+  uint8_t *d_cam_buf[2];
+  size_t cam_lds_offset;         // of the LDS images inside a camera block
   size_t cam_bytes;              // (with the padding the many-sphere staging may read over)
   size_t cam_bytes_used;         // what a camera move has to copy
   bool has_b;                    // two orderings (an enclosing sphere)
@@ -197,15 +201,23 @@ struct rt_scene_dev {
   struct camera_use { uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles, part; uint64_t cam_gen; uint32_t uses; };
   std::vector<camera_use> camera_uses;
   hipStream_t last_stream = nullptr;     // the stream of the scene's last launch; several: launches of this scene are in flight on more than one
-  bool any_launch = false, several_streams = false;
-  hipStream_t cam_stream = nullptr;      // the stream the camera block was last written on, and the event behind that copy
-  hipEvent_t cam_ready = nullptr;
+  bool any_launch = false, several_streams = false, launched_since_move = false;
+  // The camera pipeline (rt_scene_set_camera).  `side`: a stream of the scene's own, on which a move's camera block is copied and the
+  // launch tables of the frame sizes in use are rebuilt - beside the previous camera's launches, which run on the caller's stream.
+  //   old_done[x]   recorded on the caller's stream at the move to generation g (x = (g - 1) & 1): every launch with generations < g
+  //                 precedes it.  The move to g + 1 writes block / tables (g + 1) & 1 = x only behind it.
+  //   prep_done[b]  recorded on `side` behind the copy and the builds of generation g (b = g & 1): the first launch of generation g
+  //                 on a stream waits for it (prep_waited: which streams already do).
+  hipStream_t side = nullptr;
+  hipEvent_t old_done[2] = {nullptr, nullptr}, prep_done[2] = {nullptr, nullptr};
+  bool old_done_valid[2] = {false, false}, prep_valid[2] = {false, false};
+  struct waited_on { hipStream_t stream; uint64_t gen; };
+  std::vector<waited_on> prep_waited;
   // pinned staging for the small copies that follow a camera move (the camera block; a launch table's parameters): a ring of slots,
   // each guarded by an event recorded behind the copy that read it
   struct stage_slot { uint8_t *h = nullptr; hipEvent_t done = nullptr; bool used = false; };
   stage_slot stages[16];                 // (16: the host may run eight frames ahead of the GPU in an animation; one pinned allocation behind them)
   uint8_t *stage_pool = nullptr;
-  stage_slot *cam_pending = nullptr;     // a camera block staged by rt_scene_set_camera and not copied yet: the next launch's first step
   size_t stage_bytes = 0;
   uint32_t stage_next = 0;
   std::vector<uint8_t> host_blob;        // the scene as uploaded (patched: 1/r per sphere), for rebuilding the camera block
@@ -224,13 +236,16 @@ struct rt_scene_dev {
   std::vector<rt_geom> host_cull;
   std::vector<uint32_t> tile_weight;
   // One launch table per (frame size, tile set, flags), built on the GPU (rt_tables_gpu.hip) on the stream of the launch that needs
-  // it first and again, in place, when the camera has moved since (cam_gen).  `T` = its device memory; `d_block` = ONE allocation
+  // it first and again when the camera has moved since (cam_gen).  `Tb` = its device memory; `d_blockb` = ONE allocation
   // behind all of T's arrays; `n_blocks` workgroups are launched until the host has seen the number of entries the build published
   // (`known`: generation << 32 | entries + 1, a pinned host word), from then on exactly that many.
   struct order_entry {
     uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t part;
-    uint64_t cam_gen; uint32_t n_blocks; size_t hist_words; rt_table_dev T; uint8_t *d_block; volatile unsigned long long *known; hipStream_t built_on; hipEvent_t built;
+    uint64_t cam_gen; uint32_t n_blocks; volatile unsigned long long *known; hipStream_t built_on; hipEvent_t built;
     bool shared;                   // launched with on a stream other than the one it was built on
+    // two tables, like the camera blocks: generation g's is Tb[g & 1] (the next camera's is built while this one's is still read)
+    rt_table_dev Tb[2]; uint8_t *d_blockb[2]; size_t hist_wordsb[2];
+    uint64_t used_gen;             // the last camera generation a launch used it with: a move rebuilds the tables in use ahead of the next render
   };
   std::vector<order_entry> orders;
   uint32_t order_evict = 0;
@@ -368,10 +383,12 @@ namespace {
 constexpr size_t RT_KNOWN_WORDS = 256;
 
 void free_order_entry(rt_scene_dev::order_entry &e) {
-  if (e.d_block) (void)hipFree(e.d_block);
+  for (int b = 0; b < 2; b++) { if (e.d_blockb[b]) (void)hipFree(e.d_blockb[b]); e.d_blockb[b] = nullptr; }
   if (e.built) (void)hipEventDestroy(e.built);
-  e.d_block = nullptr; e.built = nullptr;
+  e.built = nullptr;
 }
+inline uint8_t *cam_block(const rt_scene_dev *s) { return s->d_cam_buf[s->cam_gen & 1u]; }
+inline uint8_t *lds_image_of(const rt_scene_dev *s) { return s->cull_in_lds ? cam_block(s) + s->cam_lds_offset : s->d_lds_image; }
 
 // [materials (rt_mtl) | 16 texture descriptors | cull rectangles (few spheres)] of ordering `ord`: the workgroup's LDS image
 void fill_lds_image(const rt_scene_dev *s, uint8_t *dst, int ord) {
@@ -413,7 +430,7 @@ void fill_camera_block(const rt_scene_dev *s, uint8_t *dst) {
     }
   }
   if (s->cull_in_lds) {
-    uint8_t *img = dst + (((size_t)n_ord * 2u * NO * sizeof(rt_geom) + 255u) & ~(size_t)255u);
+    uint8_t *img = dst + s->cam_lds_offset;
     for (int ord = 0; ord < n_ord; ord++) fill_lds_image(s, img + ord * s->lds_image_bytes, ord);
   }
 }
@@ -429,16 +446,6 @@ void camera_decisions(rt_scene_dev *s) {
   // that only has to RANK tiles: lit hits 2, one more per bounce a reflective or refractive hit can spawn, and the binary tree
   // of a sphere that does both (main.js:268-278) its node count; pure-ambient spheres (the reference's skybox) nothing
   scene_tile_weights(hd, ob, &s->host_cull, &s->tile_weight);
-}
-
-// behind the launch that copied the staged camera block on `stream`
-hipError_t camera_copied(rt_scene_dev *s, rt_scene_dev::stage_slot *cam, hipStream_t stream) {
-  hipError_t e = hipEventRecord(cam->done, stream);
-  if (e == hipSuccess && !s->cam_ready) e = hipEventCreateWithFlags(&s->cam_ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(s->cam_ready, stream);
-  s->cam_stream = stream;
-  s->cam_pending = nullptr;
-  return e;
 }
 
 // a staging slot of `bytes` (<= stage_bytes), free to be written: its previous copy has been read
@@ -460,7 +467,7 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   const rt_scene_header *hd = (const rt_scene_header *)blob;
   rt_scene_dev *s = new rt_scene_dev();
   s->device = device; s->hd = *hd; s->d_blob = nullptr; s->d_texdesc = nullptr; s->d_geom = nullptr; s->d_objects_b = nullptr; s->d_lds_image = nullptr; s->d_shadow_grid = nullptr; s->d_bounce_table = nullptr;
-  s->d_cam = nullptr;
+  s->d_cam_buf[0] = s->d_cam_buf[1] = nullptr;
   const uint8_t *base = (const uint8_t *)blob;
   const rt_sphere *ob = (const rt_sphere *)(base + hd->objects_offset);
   s->refract = false;
@@ -574,10 +581,11 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   const size_t off_img = at; at = up(at + (s->cull_in_lds ? 0 : s->lds_image_bytes * n_ord + 4096u));   // the many-sphere kernel reads whole 4 KB pieces (rt_kernel.hip staging)
   const size_t off_sg = at; at = up(at + sg.size() * sizeof(uint64_t));
   const size_t off_bt = at; at = up(at + bt.size() * sizeof(uint64_t));
-  const size_t off_cam = at;
-  s->cam_bytes_used = up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) + (s->cull_in_lds ? s->lds_image_bytes * n_ord : 0);
+  s->cam_lds_offset = up((size_t)n_ord * 2u * NO * sizeof(rt_geom));
+  s->cam_bytes_used = s->cam_lds_offset + (s->cull_in_lds ? s->lds_image_bytes * n_ord : 0);
   s->cam_bytes = s->cam_bytes_used + (s->cull_in_lds ? 4096u : 0);
-  at = up(at + s->cam_bytes);
+  const size_t off_cam0 = at; at = up(at + s->cam_bytes);
+  const size_t off_cam1 = at; at = up(at + s->cam_bytes);
   s->arena_bytes = at;
   std::vector<uint8_t> host(at, 0);
   memcpy(host.data() + off_blob, s->host_blob.data(), bytes);
@@ -601,7 +609,8 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   // the LDS images' camera-independent part: [materials | texture descriptors] (fill_camera_block below writes them again, with
   // their cull rectangles, when they live in the camera block)
   if (!s->cull_in_lds) for (int ord = 0; ord < n_ord; ord++) fill_lds_image(s, host.data() + off_img + ord * s->lds_image_bytes, ord);
-  fill_camera_block(s, host.data() + off_cam);
+  fill_camera_block(s, host.data() + off_cam0);
+  memcpy(host.data() + off_cam1, host.data() + off_cam0, s->cam_bytes_used);
   // ---- one allocation, one copy ----
   hipError_t e = hipMalloc((void **)&s->arena, s->arena_bytes);
   if (e == hipSuccess) e = hipMemcpy(s->arena, host.data(), s->arena_bytes, hipMemcpyHostToDevice);
@@ -626,8 +635,8 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
   s->d_objects_b = has_b ? (rt_sphere *)(s->arena + off_objs_b) : nullptr;
   s->d_shadow_grid = sg.empty() ? nullptr : (uint64_t *)(s->arena + off_sg);
   s->d_bounce_table = bt.empty() ? nullptr : (uint64_t *)(s->arena + off_bt);
-  s->d_cam = s->arena + off_cam;
-  s->d_lds_image = s->cull_in_lds ? s->d_cam + up((size_t)n_ord * 2u * NO * sizeof(rt_geom)) : s->arena + off_img;
+  s->d_cam_buf[0] = s->arena + off_cam0; s->d_cam_buf[1] = s->arena + off_cam1;
+  s->d_lds_image = s->cull_in_lds ? nullptr : s->arena + off_img;
   *out = s;
   return RT_OK;
 }
@@ -639,7 +648,8 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
   if (s->arena) (void)hipFree(s->arena);
   for (rt_scene_dev::stage_slot &g : s->stages) if (g.done) (void)hipEventDestroy(g.done);
   if (s->stage_pool) (void)hipHostFree(s->stage_pool);
-  if (s->cam_ready) (void)hipEventDestroy(s->cam_ready);
+  for (int b = 0; b < 2; b++) { if (s->old_done[b]) (void)hipEventDestroy(s->old_done[b]); if (s->prep_done[b]) (void)hipEventDestroy(s->prep_done[b]); }
+  if (s->side) (void)hipStreamDestroy(s->side);
   for (rt_scene_dev::order_entry &e : s->orders) free_order_entry(e);
   for (const rt_scene_dev::mark_state &m : s->mark_states) (void)hipFree(m.d_marks);
   if (s->h_known_pool) (void)hipHostFree(s->h_known_pool);
@@ -647,16 +657,23 @@ extern "C" void rt_scene_free(rt_scene_dev *s) {
 }
 
 // The camera of a resident scene moves (lookAt, main.js:92-100; the reference recomputes everything per redraw, main.js:180-201).
-// What depends on it - the camera-anchored geometry, the cull rectangles, the LDS images that hold them - is ONE block of the
-// scene's arena; it is staged here (pinned host memory) and copied by the NEXT launch of the scene, on that launch's stream, by one
-// small kernel that also carries the parameters of the launch table that launch rebuilds on the GPU (dispatch_order).  Nothing
-// waits for the GPU unless launches of this scene are in flight on ANOTHER stream than that one (then the device is drained first:
-// they may still read the old block).
+// What depends on it - the camera-anchored geometry, the cull rectangles, the LDS images that hold them (ONE block of the scene's
+// arena) and the launch tables of the frame sizes in use - exists twice, for even and odd camera generations.  The move stages the
+// new block (pinned host memory) and, on the scene's OWN side stream, copies it and rebuilds the tables the previous camera's frames
+// used: beside those frames' launches, which are still running on the caller's stream, and ordered against them by two events
+// (rt_scene_dev: old_done, prep_done).  A plain `set_camera; render; set_camera; render ...` loop on one stream thereby overlaps frame
+// k + 1's table build with frame k's trace - what round 3 needed two scene handles on two streams for.  Nothing waits on the host
+// unless launches of this scene are in flight on several caller streams (then the device is drained first).
+namespace {
+bool build_table(rt_scene_dev *s, int found, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, hipStream_t stream,
+                 rt_scene_dev::stage_slot *cam);
+}  // namespace
+
 extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], const double axis_x[3], const double axis_y[3], const double axis_z[3], void *hip_stream) {
   if (!s || !origin || !axis_x || !axis_y || !axis_z) return fail(RT_ERR_INVALID, "rt_scene_set_camera: NULL argument");
   int rc = ensure_device(s->device);
   if (rc) return rc;
-  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[s->device].stream;
+  (void)hip_stream;                                  // (kept in the signature: the copy and the rebuilds run on the scene's own side stream)
   std::lock_guard<std::mutex> lk(s->launch_mu);
   rt_scene_header nh = s->hd;
   memcpy(nh.cam_origin, origin, 24); memcpy(nh.cam_axis_x, axis_x, 24); memcpy(nh.cam_axis_y, axis_y, 24); memcpy(nh.cam_axis_z, axis_z, 24);
@@ -664,19 +681,55 @@ extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], cons
   // the two orderings of the scene's tables are built around the sphere that encloses everything INCLUDING the camera
   if (enclosing_sphere(&nh, s->host_objects.data(), s->lights) != s->enclosing)
     return fail(RT_ERR_UNSUPPORTED, "rt_scene_set_camera: the camera crossed the enclosing sphere (the scene's tables are laid out around it): upload the scene again");
-  (void)stream;
+  if (!s->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) { HIP_TRY(hipEventCreateWithFlags(&s->old_done[b], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->prep_done[b], hipEventDisableTiming)); }
+  }
+  // launches of this scene in flight on SEVERAL caller streams: no single event covers them (rare: drain the device)
+  if (s->any_launch && s->several_streams) { HIP_TRY(hipDeviceSynchronize()); s->any_launch = false; s->several_streams = false; s->launched_since_move = false; s->old_done_valid[0] = s->old_done_valid[1] = false; }
+  const uint64_t old_gen = s->cam_gen;
   s->hd = nh;
   memcpy(s->host_blob.data(), &nh, sizeof nh);
   camera_decisions(s);
-  s->cam_gen++;
+  const uint64_t G = ++s->cam_gen;
+  const uint32_t b = (uint32_t)(G & 1u);
   s->renders_with_camera = 0;
-  // the block is staged now and copied by the next launch of the scene, on that launch's stream, together with what else that
-  // launch has to copy (a launch table's parameters): one small kernel
-  if (s->cam_pending) s->cam_pending->used = false;         // (a move nobody rendered: its slot is free again)
+  // every launch so far (generations < G) precedes this event on the caller's stream; the move to G + 1 will write block / tables
+  // (G + 1) & 1 - the ones generation G - 1 used - only behind it.  (No launch since the last move: the older record still covers them.)
+  if (s->launched_since_move && s->any_launch) { HIP_TRY(hipEventRecord(s->old_done[(G - 1u) & 1u], s->last_stream)); s->old_done_valid[(G - 1u) & 1u] = true; }
+  s->launched_since_move = false;
+  // block and tables b were last read by generation G - 2
+  if (s->old_done_valid[b]) HIP_TRY(hipStreamWaitEvent(s->side, s->old_done[b], 0));
   rt_scene_dev::stage_slot *slot = nullptr;
   uint8_t *st = acquire_stage(s, &slot);
   fill_camera_block(s, st);
-  s->cam_pending = slot;
+  // the tables the previous camera's frames used are rebuilt now, on the side stream, beside those frames' launches: the next render
+  // of such a frame finds its table (up to four; others are built by the launch that needs them, on its stream).  Many-sphere scenes:
+  // the first frame from a camera takes the table without shadow masks (rt_render_batch: masks_pay).
+  const uint32_t n_loop = s->hd.n_objects - (s->enclosing != ~0u ? 1u : 0u);
+  int built = 0;
+  bool cam_sent = false;
+  for (size_t i = 0; i < s->orders.size() && built < 4; i++) {
+    rt_scene_dev::order_entry &e = s->orders[i];
+    if (e.used_gen != old_gen || !e.built || (n_loop > 16u && e.masks)) continue;
+    const rt_tiles tiles = {e.tile_rows, e.tile_first, e.tile_stride, e.n_tiles};
+    const bool ss2 = e.ss == 2u;
+    const uint32_t rows_per_wg = ss2 ? 2u : RT_TILE_H;
+    const uint32_t tiles_x = (e.w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (e.tile_rows + rows_per_wg - 1) / rows_per_wg;
+    const double sw = ss2 ? 2.0 * e.w : (double)e.w, sh = ss2 ? 2.0 * e.h : (double)e.h;        // (the expressions of render_batch_impl: the same bits)
+    const double projA = s->hd.fov_deg * M_PI / 180.0, pw = sw / 2.0, ph = sh / 2.0, pd = pw / tan(projA / 2.0);
+    if (!build_table(s, (int)i, &tiles, tiles_x, rb_per_tile, pw, ph, pd, s->side, cam_sent ? nullptr : slot)) return RT_ERR_DEVICE;
+    cam_sent = true;
+    built++;
+  }
+  if (!cam_sent) {
+    hipError_t e = (hipError_t)rt_launch_small_copy(cam_block(s), st, s->cam_bytes_used, nullptr, nullptr, 0u, s->side);
+    if (e == hipSuccess) e = hipEventRecord(slot->done, s->side);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "camera block: %s", hipGetErrorString(e));
+  }
+  HIP_TRY(hipEventRecord(s->prep_done[b], s->side));
+  s->prep_valid[b] = true;
+  s->prep_waited.clear();
   return RT_OK;
 }
 
@@ -753,9 +806,84 @@ uint32_t known_value(const volatile unsigned long long *p, uint64_t gen) {
   return (uint32_t)(v >> 32) == (uint32_t)gen ? (uint32_t)v : 0u;
 }
 
-// The launch table of this (frame size, tile set, flags) for the scene's CURRENT camera: found, or built on the GPU - three small
-// launches on `stream` (rt_tables_gpu.hip), behind one small copy of its parameters; nothing waits for them.  Called with the
-// scene's launch_mu held.  Returns the entry's index, or -1 (rt_last_error says why).
+// Build the launch table of entry `found` for the scene's CURRENT camera (generation g, into the entry's table g & 1) on `stream`:
+// one small copy of its parameters - which also carries the staged camera block `cam` of a move, if given - and three small launches
+// (rt_tables_gpu.hip); nothing waits for them.  Called with the scene's launch_mu held.  false: rt_last_error says why.
+bool build_table(rt_scene_dev *s, int found, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, hipStream_t stream,
+                 rt_scene_dev::stage_slot *cam) {
+  rt_scene_dev::order_entry &e = s->orders[found];
+  const uint32_t tb = (uint32_t)(s->cam_gen & 1u);
+  rt_table_params P;
+  std::vector<rt_ball> balls;
+  std::vector<rt_cost_rect> rects;
+  if (make_table_params(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, e.w, e.h, e.ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, e.ranked, e.sky,
+                        s->enclosing, e.masks, e.cands, s->lights, &P, &balls, &rects)) {
+    fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile);
+    return false;
+  }
+  P.flags |= e.part == 1u ? RT_TABLE_NO_SKY : (e.part == 2u ? RT_TABLE_SKY_ONLY : 0u);
+  const uint32_t n = P.tiles_x * P.ny;
+  const size_t hist_words = (size_t)P.ny * P.cost_bins;
+  rt_table_dev &T = e.Tb[tb];
+  // the table's device memory: one allocation behind all its arrays; the per-row histograms grow with the camera's cost range
+  if (!e.d_blockb[tb] || e.hist_wordsb[tb] < hist_words) {
+    if (e.d_blockb[tb]) { (void)hipDeviceSynchronize(); (void)hipFree(e.d_blockb[tb]); e.d_blockb[tb] = nullptr; }
+    auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+    const size_t cap_hist = hist_words > (size_t)P.ny * 128u ? hist_words : (size_t)P.ny * 128u;
+    const size_t dyn_bytes = up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_cost_rect)) + 256u;
+    size_t at = 0;
+    const size_t o_dyn = at; at += dyn_bytes;
+    const size_t o_blk = at; at = up(at + (size_t)n * 12u);
+    const size_t o_item = at; at = up(at + (size_t)n * 4u);
+    const size_t o_rank = at; at = up(at + (size_t)n * 4u);
+    const size_t o_hist = at; at = up(at + cap_hist * 4u);
+    const size_t o_bins = at; at = up(at + (size_t)(RT_COST_MAX + 1u) * 4u);
+    const size_t o_head = at; at = up(at + 16u + ((size_t)(n + 7u) / 8u) * 8u * 16u);
+    uint8_t *blk = nullptr;
+    hipError_t er = hipMalloc((void **)&blk, at);
+    if (er == hipSuccess) er = hipMemsetAsync(blk + o_dyn + dyn_bytes - 256u, 0, 256u, stream);     // the scan's ticket
+    if (er == hipSuccess && !e.built) er = hipEventCreateWithFlags(&e.built, hipEventDisableTiming);
+    if (er != hipSuccess) { if (blk) (void)hipFree(blk); fail(RT_ERR_DEVICE, "launch table (%zu bytes): %s", at, hipGetErrorString(er)); return false; }
+    e.d_blockb[tb] = blk;
+    e.hist_wordsb[tb] = cap_hist;
+    T.params = (const rt_table_params *)(blk + o_dyn);
+    T.ticket = (uint32_t *)(blk + o_dyn + dyn_bytes - 256u);
+    T.blk = (uint32_t *)(blk + o_blk); T.item = (uint32_t *)(blk + o_item); T.rank_in_row = (uint32_t *)(blk + o_rank);
+    T.row_hist = (uint32_t *)(blk + o_hist); T.bin_start = (uint32_t *)(blk + o_bins);
+    T.header = (uint32_t *)(blk + o_head); T.entries = T.header + 4;
+    T.known = (unsigned long long *)e.known;
+  } else if (e.shared && stream != s->side) {
+    // rebuilt lazily on a caller's stream while launches on ANOTHER caller's stream may still read this table's older contents: only
+    // when nothing is in flight (rare; a move's own rebuilds, on the side stream, come behind old_done instead)
+    (void)hipDeviceSynchronize();
+  }
+  e.n_blocks = n;
+  e.cam_gen = s->cam_gen;
+  T.known_tag = (uint32_t)s->cam_gen;
+  e.built_on = stream; e.shared = false;
+  // parameters, cone-test spheres and cost rectangles, packed: one staging slot, ONE small copy kernel - which also carries the
+  // scene's camera block of a move (an SDMA copy in front of the build would cost two engine hand-overs, more than the copy)
+  rt_scene_dev::stage_slot *slot = nullptr;
+  uint8_t *st = acquire_stage(s, &slot);
+  const size_t o_balls = (sizeof(rt_table_params) + 15u) & ~(size_t)15u, o_rects = o_balls + balls.size() * sizeof(rt_ball);
+  const size_t copy_bytes = o_rects + rects.size() * sizeof(rt_cost_rect);
+  T.balls = (const rt_ball *)((const uint8_t *)T.params + o_balls);
+  T.rects = (const rt_cost_rect *)((const uint8_t *)T.params + o_rects);
+  memcpy(st, &P, sizeof P);
+  if (!balls.empty()) memcpy(st + o_balls, balls.data(), balls.size() * sizeof(rt_ball));
+  if (!rects.empty()) memcpy(st + o_rects, rects.data(), rects.size() * sizeof(rt_cost_rect));
+  hipError_t er = (hipError_t)rt_launch_small_copy((void *)T.params, st, copy_bytes, cam ? cam_block(s) : nullptr, cam ? cam->h : nullptr, cam ? s->cam_bytes_used : 0u, stream);
+  if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
+  if (er == hipSuccess && cam) er = hipEventRecord(cam->done, stream);
+  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, (P.flags & RT_TABLE_WIDE) ? 1 : 0, stream);
+  if (er == hipSuccess) er = hipEventRecord(e.built, stream);
+  if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return false; }
+  return true;
+}
+
+// The launch table of this (frame size, tile set, flags) for the scene's CURRENT camera: found - built by rt_scene_set_camera on the
+// scene's side stream, or by an earlier launch - or built now on `stream`.  Called with the scene's launch_mu held.  Returns the
+// entry's index, or -1 (rt_last_error says why).
 int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
                    double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t sky_part, hipStream_t stream) {
   // sky_part: 0 every entry; 1 (RT_FLAG_NO_SKY) a table without the sky runs; 2 (RT_FLAG_SKY_ONLY) a table of nothing else - tables of
@@ -768,22 +896,17 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
   }
   if (found >= 0 && s->orders[found].cam_gen == s->cam_gen) {
     rt_scene_dev::order_entry &e = s->orders[found];
-    // built on another stream: this stream's launches come behind the build
-    if (e.built_on != stream) { if (hipStreamWaitEvent(stream, e.built, 0) != hipSuccess) { fail(RT_ERR_DEVICE, "launch table: hipStreamWaitEvent"); return -1; } e.shared = true; }
+    // built on another caller's stream: this stream's launches come behind the build (the side stream's builds: behind prep_done,
+    // which every stream waits for before its first launch with a camera)
+    if (e.built_on != stream && e.built_on != s->side) { if (hipStreamWaitEvent(stream, e.built, 0) != hipSuccess) { fail(RT_ERR_DEVICE, "launch table: hipStreamWaitEvent"); return -1; } e.shared = true; }
+    e.used_gen = s->cam_gen;
     return found;
   }
-  rt_table_params P;
-  std::vector<rt_ball> balls;
-  std::vector<rt_cost_rect> rects;
-  if (make_table_params(&s->hd, s->host_objects.data(), s->host_cull, s->tile_weight, w, h, ss, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, ranked, mark_sky,
-                        s->enclosing, shadow_masks, name_candidates, s->lights, &P, &balls, &rects)) {
-    fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile);
-    return -1;
-  }
-  P.flags |= sky_part == 1u ? RT_TABLE_NO_SKY : (sky_part == 2u ? RT_TABLE_SKY_ONLY : 0u);
-  const uint32_t n = P.tiles_x * P.ny;
-  const size_t hist_words = (size_t)P.ny * P.cost_bins;
   if (found < 0) {
+    if ((uint64_t)tiles_x * tiles->n_tiles * rb_per_tile >= (1ull << 31) || tiles_x > 2048u) {
+      fail(RT_ERR_INVALID, "a launch of %llu workgroups is beyond the launch table", (unsigned long long)tiles_x * tiles->n_tiles * rb_per_tile);
+      return -1;
+    }
     // a scene that has been rendered with 64 different (frame size, tile set) pairs gives up its oldest table (nothing of it may be
     // in flight: the device is drained first; rare)
     if (s->orders.size() >= 64u) {
@@ -802,58 +925,8 @@ int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const r
     e.known = known_word(s, RT_KNOWN_WORDS + (size_t)found);
     if (e.known) *e.known = 0ull;                        // (a table evicted from this slot may have published its count for the same camera)
   }
-  rt_scene_dev::order_entry &e = s->orders[found];
-  // the table's device memory: one allocation behind all its arrays; the per-row histograms grow with the camera's cost range
-  if (!e.d_block || e.hist_words < hist_words) {
-    if (e.d_block) { (void)hipDeviceSynchronize(); (void)hipFree(e.d_block); e.d_block = nullptr; }
-    auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
-    const size_t cap_hist = hist_words > (size_t)P.ny * 128u ? hist_words : (size_t)P.ny * 128u;
-    const size_t dyn_bytes = up(sizeof(rt_table_params)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_ball)) + up((size_t)RT_MAX_OBJECTS * sizeof(rt_cost_rect)) + 256u;
-    size_t at = 0;
-    const size_t o_dyn = at; at += dyn_bytes;
-    const size_t o_blk = at; at = up(at + (size_t)n * 12u);
-    const size_t o_item = at; at = up(at + (size_t)n * 4u);
-    const size_t o_rank = at; at = up(at + (size_t)n * 4u);
-    const size_t o_hist = at; at = up(at + cap_hist * 4u);
-    const size_t o_bins = at; at = up(at + (size_t)(RT_COST_MAX + 1u) * 4u);
-    const size_t o_head = at; at = up(at + 16u + ((size_t)(n + 7u) / 8u) * 8u * 16u);
-    hipError_t er = hipMalloc((void **)&e.d_block, at);
-    if (er == hipSuccess) er = hipMemsetAsync(e.d_block + o_dyn + dyn_bytes - 256u, 0, 256u, stream);     // the scan's ticket
-    if (er == hipSuccess && !e.built) er = hipEventCreateWithFlags(&e.built, hipEventDisableTiming);
-    if (er != hipSuccess) { fail(RT_ERR_DEVICE, "launch table (%zu bytes): %s", at, hipGetErrorString(er)); return -1; }
-    e.hist_words = cap_hist;
-    e.T.params = (const rt_table_params *)(e.d_block + o_dyn);
-    e.T.ticket = (uint32_t *)(e.d_block + o_dyn + dyn_bytes - 256u);
-    e.T.blk = (uint32_t *)(e.d_block + o_blk); e.T.item = (uint32_t *)(e.d_block + o_item); e.T.rank_in_row = (uint32_t *)(e.d_block + o_rank);
-    e.T.row_hist = (uint32_t *)(e.d_block + o_hist); e.T.bin_start = (uint32_t *)(e.d_block + o_bins);
-    e.T.header = (uint32_t *)(e.d_block + o_head); e.T.entries = e.T.header + 4;
-    e.T.known = (unsigned long long *)e.known;
-  } else if (e.shared || e.built_on != stream) {
-    (void)hipDeviceSynchronize();                        // the old table may still be read on another stream: rebuilt only when nothing is in flight (rare)
-  }
-  e.n_blocks = n;
-  e.cam_gen = s->cam_gen;
-  e.T.known_tag = (uint32_t)s->cam_gen;
-  e.built_on = stream; e.shared = false;
-  // parameters, cone-test spheres and cost rectangles, packed: one staging slot, ONE small copy kernel - which also carries the
-  // scene's camera block if the camera has moved since the last launch (an SDMA copy in front of the build would cost two engine
-  // hand-overs, more than the copy)
-  rt_scene_dev::stage_slot *slot = nullptr;
-  uint8_t *st = acquire_stage(s, &slot);
-  const size_t o_balls = (sizeof(rt_table_params) + 15u) & ~(size_t)15u, o_rects = o_balls + balls.size() * sizeof(rt_ball);
-  const size_t copy_bytes = o_rects + rects.size() * sizeof(rt_cost_rect);
-  e.T.balls = (const rt_ball *)((const uint8_t *)e.T.params + o_balls);
-  e.T.rects = (const rt_cost_rect *)((const uint8_t *)e.T.params + o_rects);
-  memcpy(st, &P, sizeof P);
-  if (!balls.empty()) memcpy(st + o_balls, balls.data(), balls.size() * sizeof(rt_ball));
-  if (!rects.empty()) memcpy(st + o_rects, rects.data(), rects.size() * sizeof(rt_cost_rect));
-  rt_scene_dev::stage_slot *cam = s->cam_pending;
-  hipError_t er = (hipError_t)rt_launch_small_copy((void *)e.T.params, st, copy_bytes, cam ? s->d_cam : nullptr, cam ? cam->h : nullptr, cam ? s->cam_bytes_used : 0u, stream);
-  if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
-  if (er == hipSuccess && cam) er = camera_copied(s, cam, stream);
-  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&e.T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, (P.flags & RT_TABLE_WIDE) ? 1 : 0, stream);
-  if (er == hipSuccess) er = hipEventRecord(e.built, stream);
-  if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return -1; }
+  if (!build_table(s, found, tiles, tiles_x, rb_per_tile, proj_w, proj_h, proj_d, stream, nullptr)) return -1;
+  s->orders[found].used_gen = s->cam_gen;
   return found;
 }
 
@@ -879,11 +952,12 @@ extern "C" int rt_test_launch_table(rt_scene_dev *s, uint32_t w, uint32_t h, con
   HIP_TRY(hipStreamSynchronize(stream));
   const rt_scene_dev::order_entry &e = s->orders[oi];
   uint32_t header[4];
-  HIP_TRY(hipMemcpy(header, e.T.header, sizeof header, hipMemcpyDeviceToHost));
+  const rt_table_dev &T = e.Tb[s->cam_gen & 1u];
+  HIP_TRY(hipMemcpy(header, T.header, sizeof header, hipMemcpyDeviceToHost));
   if (known_value(e.known, s->cam_gen) != header[0] + 1u) return fail(RT_ERR_STATE, "the build published %u entries to the host, its header says %u", known_value(e.known, s->cam_gen), header[0] + 1u);
   *n_workgroups = header[0];
   if (n_blocks) *n_blocks = e.n_blocks;
-  if (out_entries) HIP_TRY(hipMemcpy(out_entries, e.T.entries, (size_t)((e.n_blocks + 7u) / 8u) * 8u * 16u, hipMemcpyDeviceToHost));
+  if (out_entries) HIP_TRY(hipMemcpy(out_entries, T.entries, (size_t)((e.n_blocks + 7u) / 8u) * 8u * 16u, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 #endif
@@ -1062,13 +1136,20 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   {
     // which streams the scene's launches run on (rt_scene_set_camera, dispatch_order), and: behind the last write of the camera block
     std::lock_guard<std::mutex> lk(s->launch_mu);
-    if (s->cam_pending) {
-      // the camera has moved: launches of this scene still in flight on ANOTHER stream may read the old block (rare: drain the device)
-      if (s->any_launch && (s->several_streams || s->last_stream != stream)) HIP_TRY(hipDeviceSynchronize());
-      s->any_launch = false; s->several_streams = false;
-    } else if (s->cam_ready && s->cam_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->cam_ready, 0));
+    // the camera has moved since this stream last launched the scene: behind the copy of its block and the tables rebuilt for it
+    // (the scene's side stream, rt_scene_set_camera)
+    const uint32_t cb = (uint32_t)(s->cam_gen & 1u);
+    if (s->prep_valid[cb]) {
+      bool waits = false;
+      for (const rt_scene_dev::waited_on &q : s->prep_waited) if (q.stream == stream && q.gen == s->cam_gen) waits = true;
+      if (!waits) {
+        HIP_TRY(hipStreamWaitEvent(stream, s->prep_done[cb], 0));
+        if (s->prep_waited.size() >= 16u) s->prep_waited.clear();
+        s->prep_waited.push_back(rt_scene_dev::waited_on{stream, s->cam_gen});
+      }
+    }
     if (s->any_launch && s->last_stream != stream) s->several_streams = true;
-    s->last_stream = stream; s->any_launch = true;
+    s->last_stream = stream; s->any_launch = true; s->launched_since_move = true;
   }
 
   const rt_scene_header &hd = s->hd;
@@ -1099,13 +1180,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     const bool plain = strict || count;
     const bool order_b = s->d_objects_b && !plain;
     const rt_geom *gt = s->d_geom + (order_b ? (size_t)hd.n_objects * (1 + hd.n_lights) : 0);      // [plain N | anchored at light k: NL x N]
-    const rt_geom *gc = (const rt_geom *)s->d_cam + (order_b ? 2 * (size_t)hd.n_objects : 0);          // camera block: [anchored at the camera N | cull rectangles N]
+    const rt_geom *gc = (const rt_geom *)cam_block(s) + (order_b ? 2 * (size_t)hd.n_objects : 0);     // this camera's block: [anchored at the camera N | cull rectangles N]
     K.objects = order_b ? s->d_objects_b : (const rt_sphere *)(db + hd.objects_offset);
     K.geom = gt;
     K.geom_cam = gc;
     K.cull = gc + hd.n_objects;
     K.geom_light = gt + hd.n_objects;
-    K.lds_image = s->d_lds_image + (order_b ? s->lds_image_bytes : 0);
+    K.lds_image = lds_image_of(s) + (order_b ? s->lds_image_bytes : 0);
     K.shadow_grid = (!plain && !no_grid) ? s->d_shadow_grid : nullptr;
     K.bounce_table = (!plain && !no_bounce) ? s->d_bounce_table : nullptr;
     K.n_loop = order_b ? hd.n_objects - 1 : hd.n_objects;
@@ -1199,11 +1280,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // (the strict kernels know no sky blocks: the RT_FLAG_NO_SKY calls of such a launch store every pixel, this one none)
   } else if (strict_main) {
     std::lock_guard<std::mutex> lk(s->launch_mu);
-    if (rt_scene_dev::stage_slot *cam = s->cam_pending) {          // the camera has moved: its block first
-      hipError_t e = (hipError_t)rt_launch_small_copy(s->d_cam, cam->h, s->cam_bytes_used, nullptr, nullptr, 0u, stream);
-      if (e == hipSuccess) e = camera_copied(s, cam, stream);
-      if (e != hipSuccess) return fail(RT_ERR_DEVICE, "camera block: %s", hipGetErrorString(e));
-    }
     {
       size_t per_lane = 0;
       if ((rc = kernel_scratch(true, false, s->refract, count, ss2, 0, &per_lane))) return rc;
@@ -1251,7 +1327,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
                                   shadow_masks, name_candidates, sky_part, stream);
     if (oi < 0) return RT_ERR_DEVICE;
     rt_scene_dev::order_entry &oe = s->orders[oi];
-    L.order = oe.T.entries;
+    L.order = oe.Tb[s->cam_gen & 1u].entries;
     // one workgroup per table entry (runs of sky blocks share one).  How many there are is known on the device; until the build's
     // count has reached the host, one workgroup per BLOCK is launched: those behind the last entry read a zero slot and leave
     const uint32_t n_known = known_value(oe.known, s->cam_gen);

@@ -199,11 +199,15 @@ int rt_scene_upload(int device, const void *scene_blob, size_t blob_bytes, rt_sc
 void rt_scene_free(rt_scene_dev *scene);
 
 /* Move the camera of a resident scene (the reference's lookAt(), main.js:92-100: origin and the three axes; the reference
- * recomputes everything on every redraw, main.js:180-201).  One small asynchronous copy on `hip_stream` (NULL = the library's
- * stream for that device); what the library derives from the camera per frame size - the launch table - is rebuilt ON THE GPU by
- * the next render, on its stream, with no host wait.  Renders and camera moves of one scene belong on ONE stream (others work:
- * the device is drained first).  A camera that crosses the scene's enclosing sphere (a skybox) is RT_ERR_UNSUPPORTED: upload the
- * scene again. */
+ * recomputes everything on every redraw, main.js:180-201).  Asynchronous: what depends on the camera - one small block of the
+ * resident scene and, per frame size in use, the launch table - exists twice (even / odd camera generations); the move copies the
+ * new block and rebuilds those tables ON THE GPU on a stream of the library's own, beside the previous camera's frames that are
+ * still rendering, and the next render of the scene waits for them by event (no host wait).  A plain loop
+ * `rt_scene_set_camera; rt_render_tiles_device; ...` on ONE stream therefore overlaps a frame's table build with its predecessor's
+ * trace.  `hip_stream` is accepted for source compatibility and not used.  Renders of one scene belong on one stream (several
+ * work: a move then drains the device first).  Camera moves and renders of ONE scene handle must not be issued concurrently from
+ * different threads (renders among themselves may).  A camera that crosses the scene's enclosing sphere (a skybox) is
+ * RT_ERR_UNSUPPORTED: upload the scene again. */
 int rt_scene_set_camera(rt_scene_dev *scene, const double origin[3], const double axis_x[3], const double axis_y[3], const double axis_z[3],
                         void *hip_stream);
 
