@@ -806,6 +806,18 @@ uint32_t known_value(const volatile unsigned long long *p, uint64_t gen) {
   return (uint32_t)(v >> 32) == (uint32_t)gen ? (uint32_t)v : 0u;
 }
 
+// The camera has moved since `stream` last launched the scene: its work comes behind the copy of the camera's block and the tables
+// rebuilt for it on the scene's side stream (rt_scene_set_camera).  One event wait per (stream, camera); launch_mu held.
+int behind_the_camera(rt_scene_dev *s, hipStream_t stream) {
+  const uint32_t cb = (uint32_t)(s->cam_gen & 1u);
+  if (!s->prep_valid[cb]) return RT_OK;
+  for (const rt_scene_dev::waited_on &q : s->prep_waited) if (q.stream == stream && q.gen == s->cam_gen) return RT_OK;
+  HIP_TRY(hipStreamWaitEvent(stream, s->prep_done[cb], 0));
+  if (s->prep_waited.size() >= 16u) s->prep_waited.clear();
+  s->prep_waited.push_back(rt_scene_dev::waited_on{stream, s->cam_gen});
+  return RT_OK;
+}
+
 // Build the launch table of entry `found` for the scene's CURRENT camera (generation g, into the entry's table g & 1) on `stream`:
 // one small copy of its parameters - which also carries the staged camera block `cam` of a move, if given - and three small launches
 // (rt_tables_gpu.hip); nothing waits for them.  Called with the scene's launch_mu held.  false: rt_last_error says why.
@@ -946,6 +958,7 @@ extern "C" int rt_test_launch_table(rt_scene_dev *s, uint32_t w, uint32_t h, con
   const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
   const double pw = (double)w * ss / 2.0, ph = (double)h * ss / 2.0, pd = pw / tan(s->hd.fov_deg * M_PI / 180.0 / 2.0);
   std::lock_guard<std::mutex> lk(s->launch_mu);
+  if ((rc = behind_the_camera(s, stream))) return rc;
   const int oi = dispatch_order(s, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, (ranked & 1) != 0, (ranked & 2) != 0, (ranked & 4) != 0, (ranked & 4) != 0,
                                 (ranked & 8) ? 1u : ((ranked & 16) ? 2u : 0u), stream);
   if (oi < 0) return RT_ERR_DEVICE;
@@ -1136,18 +1149,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   {
     // which streams the scene's launches run on (rt_scene_set_camera, dispatch_order), and: behind the last write of the camera block
     std::lock_guard<std::mutex> lk(s->launch_mu);
-    // the camera has moved since this stream last launched the scene: behind the copy of its block and the tables rebuilt for it
-    // (the scene's side stream, rt_scene_set_camera)
-    const uint32_t cb = (uint32_t)(s->cam_gen & 1u);
-    if (s->prep_valid[cb]) {
-      bool waits = false;
-      for (const rt_scene_dev::waited_on &q : s->prep_waited) if (q.stream == stream && q.gen == s->cam_gen) waits = true;
-      if (!waits) {
-        HIP_TRY(hipStreamWaitEvent(stream, s->prep_done[cb], 0));
-        if (s->prep_waited.size() >= 16u) s->prep_waited.clear();
-        s->prep_waited.push_back(rt_scene_dev::waited_on{stream, s->cam_gen});
-      }
-    }
+    if ((rc = behind_the_camera(s, stream))) return rc;
     if (s->any_launch && s->last_stream != stream) s->several_streams = true;
     s->last_stream = stream; s->any_launch = true; s->launched_since_move = true;
   }
