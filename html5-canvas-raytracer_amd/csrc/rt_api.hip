@@ -682,7 +682,11 @@ extern "C" int rt_scene_set_camera(rt_scene_dev *s, const double origin[3], cons
   if (enclosing_sphere(&nh, s->host_objects.data(), s->lights) != s->enclosing)
     return fail(RT_ERR_UNSUPPORTED, "rt_scene_set_camera: the camera crossed the enclosing sphere (the scene's tables are laid out around it): upload the scene again");
   if (!s->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    // HIGH priority: its few hundred waves are launched INTO a chip the previous frame's trace keeps full; at normal priority the
+    // table build's workgroups waited for slots and took 77 us instead of 20 (profiles/r04_ab_log.md)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_hi));
     for (int b = 0; b < 2; b++) { HIP_TRY(hipEventCreateWithFlags(&s->old_done[b], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->prep_done[b], hipEventDisableTiming)); }
   }
   // launches of this scene in flight on SEVERAL caller streams: no single event covers them (rare: drain the device)

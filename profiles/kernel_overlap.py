@@ -2,10 +2,14 @@
 """From a rocprofv3 --kernel-trace CSV: per kernel its calls and average duration, the wall time per step of the traced loop, and how
 much of each kernel's time ran BESIDE an rt_trace launch (the camera pipeline's overlap).   python3 profiles/kernel_overlap.py <dir> [steps]"""
 import csv, glob, sys, collections
+import re
+def short(name):
+    m = re.search(r"(rt_\w+|__amd_\w+|\w+)(?=<|\(|$)", name.replace("void ", "").replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else name[:40]
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1][:40], r.get("Stream_Id", "?")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Stream_Id", "?")))
 rows.sort()
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 tail = rows[-steps * 8:] if len(rows) > steps * 8 else rows            # the loop's last kernels (steady state)
@@ -28,4 +32,4 @@ for n, (c, t, ov) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
 # gaps on the main stream: idle time between the end of a frame's last kernel and the start of the next rt_trace
 gaps = [traces[i + 1][0] - traces[i][1] for i in range(len(traces) - 1)]
 gaps.sort()
-print("between one rt_trace's end and the next one's start: median %.1f us, p90 %.1f us" % (gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3))
+if gaps: print("between one rt_trace's end and the next one's start: median %.1f us, p90 %.1f us" % (gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3))
