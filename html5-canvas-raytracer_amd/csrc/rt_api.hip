@@ -891,7 +891,7 @@ bool build_table(rt_scene_dev *s, int found, const rt_tiles *tiles, uint32_t til
   hipError_t er = (hipError_t)rt_launch_small_copy((void *)T.params, st, copy_bytes, cam ? cam_block(s) : nullptr, cam ? cam->h : nullptr, cam ? s->cam_bytes_used : 0u, stream);
   if (er == hipSuccess) er = hipEventRecord(slot->done, stream);
   if (er == hipSuccess && cam) er = hipEventRecord(cam->done, stream);
-  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, (P.flags & RT_TABLE_WIDE) ? 1 : 0, stream);
+  if (er == hipSuccess) er = (hipError_t)rt_launch_table_build(&T, P.tiles_x, P.ny, P.cost_bins, (uint32_t)copy_bytes, ((P.flags & RT_TABLE_WIDE) ? 1 : 0) | (stream == s->side ? 2 : 0), stream);
   if (er == hipSuccess) er = hipEventRecord(e.built, stream);
   if (er != hipSuccess) { e.cam_gen = 0; fail(RT_ERR_DEVICE, "launch table build: %s", hipGetErrorString(er)); return false; }
   return true;

@@ -260,12 +260,19 @@ extern "C" int rt_launch_small_copy(void *dst0, const void *pinned_src0, size_t 
 
 // Enqueue the three launches on `stream`.  Returns a hipError_t as int.
 extern "C" int rt_launch_table_build(const rt_table_dev *T, uint32_t tiles_x, uint32_t ny, uint32_t cost_bins, uint32_t dyn_bytes, int wide, hipStream_t stream) {
+  // wide & 2: the build runs BESIDE a trace kernel that keeps every CU full (rt_scene_set_camera's side stream): four-wave workgroups,
+  // which find room whenever ONE trace workgroup retires - an eight- or sixteen-wave workgroup needs two or four of them to retire on
+  // the same CU at once and waited for the trace to drain (77 us instead of 20: profiles/r04_ab_log.md)
+  const bool beside = (wide & 2) != 0;
+  wide &= 1;
   const uint32_t n = tiles_x * ny;
   const uint32_t stage_bytes = dyn_bytes <= 40u * 1024u ? ((dyn_bytes + 15u) & ~15u) : 0u;      // (params | balls | rects) of up to ~170 spheres fit LDS beside the row's arrays
   const uint32_t row_bytes = (2u * tiles_x + cost_bins) * sizeof(uint32_t);
   // few spheres (no more than 16 in the loops: per-sphere shadow sets): four work-items per block; many: eight, in 16-wave workgroups
   if (!stage_bytes) hipLaunchKernelGGL((rt_table_rows<false, 8u, 1024u>), dim3(ny), dim3(1024), row_bytes, stream, *T, 0u);
+  else if (wide && beside) hipLaunchKernelGGL((rt_table_rows<true, 8u, 256u>), dim3(ny), dim3(256), stage_bytes + row_bytes, stream, *T, stage_bytes);
   else if (wide) hipLaunchKernelGGL((rt_table_rows<true, 8u, 1024u>), dim3(ny), dim3(1024), stage_bytes + row_bytes, stream, *T, stage_bytes);
+  else if (beside) hipLaunchKernelGGL((rt_table_rows<true, 4u, 256u>), dim3(ny), dim3(256), stage_bytes + row_bytes, stream, *T, stage_bytes);
   else hipLaunchKernelGGL((rt_table_rows<true, 4u, 512u>), dim3(ny), dim3(512), stage_bytes + row_bytes, stream, *T, stage_bytes);
   hipLaunchKernelGGL(rt_table_scan, dim3(cost_bins), dim3(64), 0, stream, *T);
   hipLaunchKernelGGL(rt_table_emit, dim3((n + WG - 1u) / WG), dim3(WG), 0, stream, *T);
