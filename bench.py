@@ -1018,7 +1018,7 @@ def main():
                     out["predicted"]["measured_over_predicted_at_this_n"] = round(out["ms_per_step"] / out["predicted"]["per_n"][str(world)]["ms_per_step"], 3)
             if world == 1 and not args.no_cold and not args.strict_fp and os.environ.get("RT_BENCH_CHILD") != "1" and w * h <= 7680 * 4320:
                 try:
-                    out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(64, min(args.steps, 512))))
+                    out.update(cold_and_moving(args, scene, scene_name, w, h, lib, dev_index, stream, torch, np, max(256, min(args.steps, 512))))   # (a pipeline: 256 steps and more, so that its fill and drain do not show)
                 except Exception as e:   # noqa: BLE001  (the headline must still be reported)
                     out["cold_frame"] = {"note": "failed: %r" % (e,)}
             if world == 1 and not args.no_cold and not args.strict_fp and args.config == "cfg3" and not args.scene and os.environ.get("RT_BENCH_CHILD") != "1":

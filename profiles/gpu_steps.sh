@@ -48,13 +48,14 @@ step_configs() {            # every BASELINE config on one GPU, kernel only
   timeout -k 10 400 python profiles/bench_configs.py --big --out ${O}_configs.json > ${O}_configs.log 2>&1; rc=$?; cut -c1-200 ${O}_configs.log; return $rc
 }
 step_resources() { bash profiles/kernel_resources.sh > ${O}_kernel_resources.txt 2>&1; cat ${O}_kernel_resources.txt; }
-step_soak() {               # SOAK_NAME=<name> SOAK_N=<seeds per process> SOAK_FIRST=<first seed> [SOAK_ARGS="--camera-moves ..."] [SOAK_LIMIT=seconds]: 4 processes on the one GPU
-  for k in 0 1 2 3; do
+step_soak() {               # SOAK_NAME=<name> SOAK_N=<seeds per process> SOAK_FIRST=<first seed> [SOAK_ARGS="--camera-moves ..."] [SOAK_LIMIT=seconds] [SOAK_PROCS=4]: processes on the one GPU
+  local np=${SOAK_PROCS:-4}                      # (at most 6 processes may use the GPU together)
+  for k in $(seq 0 $((np - 1))); do
     timeout -k 10 ${SOAK_LIMIT:-500} python tests/soak_gpu_parity.py --seeds $SOAK_N --first $((SOAK_FIRST + k * SOAK_N)) --out ${O}_soak_${SOAK_NAME}_p$k.json ${SOAK_ARGS:-} > ${O}_soak_${SOAK_NAME}_p$k.log 2>&1 &
   done
   wait
-  python profiles/merge_soaks.py ${O}_soak_${SOAK_NAME}.json ${O}_soak_${SOAK_NAME}_p[0-3].json; rc=$?
-  tail -2 ${O}_soak_${SOAK_NAME}_p0.log | cut -c1-300; rm -f ${O}_soak_${SOAK_NAME}_p[0-3].json
+  python profiles/merge_soaks.py ${O}_soak_${SOAK_NAME}.json ${O}_soak_${SOAK_NAME}_p[0-9].json; rc=$?
+  tail -2 ${O}_soak_${SOAK_NAME}_p0.log | cut -c1-300; rm -f ${O}_soak_${SOAK_NAME}_p[0-9].json
   python3 -c "import json,sys; d=json.load(open('${O}_soak_${SOAK_NAME}.json')); print({k: d[k] for k in d if not isinstance(d[k], (list, dict))})" | cut -c1-900
   return $rc
 }

@@ -106,6 +106,59 @@ def draw_scene(seed, degenerate=False, many=False):
     return s, w, h
 
 
+def draw_adversarial(seed):
+    """Scenes built to stress the product kernel's boundary marks: a high-frequency sampler - the ground's checker at
+    5000 .. 1 000 000 per unit u, textured spheres - seen THROUGH two to five bounces off a tight cluster of small, nearly perfect
+    mirrors (radius 0.04 - 0.3: a mirror of radius r at distance t magnifies a direction error by ~2t/r per bounce) and small glass
+    spheres, at 3840x2160-class pixel cones (a 960-pixel-wide window of such a frame: the same projection distance, a quarter of the
+    oracle's work).  Returns (scene, w, h, tiles): two 8-row tiles through the cluster's image."""
+    rng = random.Random(seed ^ 0x2545F491)
+    base = rt_host.load_scene("default14_stars")
+    objs = []
+    for o in base["objects"]:
+        if o["r2"] >= 250000.0:
+            o = dict(o)
+            if o["r2"] > 1e6:
+                o["mtl"] = dict(o["mtl"], sampler={"kind": 0})                       # black sky
+            else:
+                f = rng.choice([5000.0, 5000.0, 20000.0, 100000.0, 1000000.0])
+                o["mtl"] = dict(o["mtl"], sampler=dict(o["mtl"]["sampler"], freqU=f, freqV=f / 2))
+            objs.append(o)
+    cx, cz = rng.uniform(-2.0, 2.0), rng.uniform(0.0, 4.0)
+    cy = rng.uniform(0.3, 1.2)
+    n_mirror, n_glass, n_tex = rng.randrange(3, 8), rng.randrange(0, 3), rng.randrange(0, 3)
+    for i in range(n_mirror + n_glass + n_tex):
+        if i < n_mirror:
+            r = rng.choice([rng.uniform(0.04, 0.12), rng.uniform(0.1, 0.3)])
+            mtl = {"color": [rng.uniform(0.5, 1.0) for _ in range(3)], "albedo": [0.0, rng.choice([0.0, 0.1, 0.3]), rng.choice([0.0, 0.2]), rng.choice([0.8, 0.95, 1.0]), 0.0],
+                   "specular_exponent": 50.0, "refract_index": 1.0, "sampler": {"kind": 0}}
+        elif i < n_mirror + n_glass:
+            r = rng.uniform(0.08, 0.3)
+            mtl = {"color": [1.0, 1.0, 1.0], "albedo": [0.0, 0.1, 0.2, rng.choice([0.0, 0.2]), rng.choice([0.8, 0.9])], "specular_exponent": 50.0,
+                   "refract_index": rng.choice([1.0, 1.3, 1.5]), "sampler": {"kind": 0}}
+        else:
+            r = rng.uniform(0.2, 0.6)
+            mtl = {"color": [1.0, 1.0, 1.0], "albedo": [rng.choice([0.0, 0.3]), 0.8, 0.1, 0.0, 0.0], "specular_exponent": 10.0, "refract_index": 1.0,
+                   "sampler": {"kind": 1, "texture": rng.randrange(3)}}
+        spread = 0.35 if i < n_mirror + n_glass else 0.9
+        objs.append({"origin": [cx + rng.uniform(-spread, spread), max(r + 0.01, cy + rng.uniform(-spread, spread)), cz + rng.uniform(-spread, spread)], "r2": r * r, "mtl": mtl})
+    w, h = 960, rng.choice([2160, 2160, 4320])
+    proj_d = (1920.0 if h == 2160 else 3840.0) / math.tan(math.radians(30.0))             # of the 3840- / 7680-wide frame at the reference's 60 degrees
+    fov = 2.0 * math.degrees(math.atan((w / 2.0) / proj_d))
+    cam_org = [cx + rng.uniform(-0.3, 0.3), rng.uniform(0.8, 2.5), cz + rng.uniform(5.0, 9.0)]
+    cam = look_at(cam_org, [cam_org[0], cam_org[1], cam_org[2] - 10.0], [0.0, 1.0, 0.0])
+    objs.sort(key=lambda o: 4 * math.pi * o["r2"] / max(math.dist(o["origin"], cam["origin"]), 1e-300))
+    s = dict(base)
+    s.update(objects=objs, camera=cam, lights=[[cx + rng.uniform(-6, 6), rng.uniform(4.0, 12.0), cz + rng.uniform(-4, 6)] for _ in range(rng.choice([1, 2, 2]))],
+             segs=rng.choice([3, 4, 5, 6]), supersample=1, fovDeg=fov, light_intensity=50.0)
+    # the cluster's image row: y = h/2 - (cy - cam_y) / depth * proj_d
+    row = h / 2.0 - (cy - cam_org[1]) / (cam_org[2] - cz) * proj_d
+    n_t = h // 8
+    t0 = min(max(int(row // 8) + rng.randrange(-3, 4), 0), n_t - 2)
+    stride = rng.randrange(1, min(6, n_t - t0))
+    return s, w, h, rt_host.RtTiles(8, t0, stride, 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=300)
@@ -119,6 +172,8 @@ def main():
                     "sky blocks (RT_FLAG_NO_SKY) plus the owner's fill (RT_FLAG_SKY_ONLY), in one buffer; must be the plain frame's bytes")
     ap.add_argument("--camera-moves", action="store_true", help="after its frame every scene gets two random camera moves (rt_scene_set_camera: the launch "
                     "table rebuilt on the GPU, mark counts forgotten); each moved frame must be the bytes a fresh upload of the moved scene renders")
+    ap.add_argument("--adversarial", action="store_true", help="scenes built against the boundary marks' tolerance: high-frequency samplers seen through 2-5 bounces off "
+                    "tight clusters of small mirrors and glass spheres, at 3840x2160-class pixel cones (draw_adversarial)")
     args = ap.parse_args()
     lib = rt_host.load_library()
     assert lib.rt_init(1) == 0, lib.rt_last_error()
@@ -152,10 +207,14 @@ def main():
     for seed in range(args.first, args.first + args.seeds):
         if stop["now"]:
             break
-        scene, w, h = draw_scene(seed, args.degenerate_lights, args.many_spheres)
-        tiles = rt_host.RtTiles(h, 0, 1, 1)
-        rows = None
-        if args.windowed:
+        if args.adversarial:
+            scene, w, h, tiles = draw_adversarial(seed)
+            rows = [8 * t + k for t in (tiles.tile_first, tiles.tile_first + tiles.tile_stride) for k in range(8)]
+        else:
+            scene, w, h = draw_scene(seed, args.degenerate_lights, args.many_spheres)
+            tiles = rt_host.RtTiles(h, 0, 1, 1)
+            rows = None
+        if args.windowed and not args.adversarial:
             wrng = random.Random(seed ^ 0x5bd1e995)
             w, h = wrng.choice([(3840, 2160), (3840, 2160), (7680, 4320)])
             scene["supersample"] = 1
