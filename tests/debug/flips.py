@@ -3,7 +3,7 @@
 
     RT_HIP_LIB=html5-canvas-raytracer_amd/csrc/librt_hip_test.so python tests/debug/flips.py 1153727 1189883 d1101 m5000 ...
 
-For each soak seed (prefix d = drawn with --degenerate-lights, m = --many-spheres) it renders the scene with both kernels
+For each soak seed (prefix d = drawn with --degenerate-lights, m = --many-spheres, a = --adversarial) it renders the scene with both kernels
 and the C restatement, lists the pixels that differ by more than 1 LSB, and for each of them (up to --max) prints the
 ray tree of that sample as the kernel walked it (rt_test_probe, test build only) next to the restatement's
 (oracle_probe_sample), node by node, marking the first node where they part.
@@ -61,9 +61,9 @@ def main():
     assert lib.rt_init(1) == 0, lib.rt_last_error()
     has_probe = hasattr(lib, "rt_test_probe")
     for spec in args.seeds:
-        deg, many = spec.startswith("d"), spec.startswith("m")
-        seed = int(spec.lstrip("dm"))
-        scene, w, h = soak.draw_scene(seed, deg, many)
+        deg, many, adv = spec.startswith("d"), spec.startswith("m"), spec.startswith("a")
+        seed = int(spec.lstrip("dma"))
+        scene, w, h = soak.draw_adversarial(seed)[:3] if adv else soak.draw_scene(seed, deg, many)
         ss = scene.get("supersample", 1)
         blob = rt_host.flatten_scene(scene)
         want = np.frombuffer(ou.c_oracle_render(blob, w, h), dtype=np.uint8).reshape(h, w, 4).astype(np.int16)
