@@ -579,6 +579,25 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   [[maybe_unused]] int sp = 0;
   [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
+#if !RT_STRICT
+  // How far this kernel's own rounding has been MAGNIFIED on the way to the current hit, as a bound on the hit's NORMAL error in units
+  // of 1.1e-16 (float: an estimate that only widens a tolerance).  A hit at distance t on a sphere of radius r met at incidence cosine
+  // c has its distance in error by ~eps t (1 + t / (r c)) - the near root t = tca - thc cancels when the ray grazes - on top of what the
+  // ray inherited, and its normal by that / r; the mirrored ray then carries ~4x the normal's error in its direction:
+  //     Q_hit = (4 Q_parent + 2) (t / r) (1 + t / (r c)),        Q = 0 at the camera.
+  // A primary hit on the floor has Q ~ 1e-2, on the reference's small spheres ~ 1e2 - 1e3; ONE grazing bounce off a sphere of radius
+  // 0.05 reaches 1e5 - 1e6 (profiles/r04_ab_log.md section 4: the adversarial soak's flipped pixel).  The samplers' boundary test
+  // scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below.  Updated per BOUNCE, not per node: `qamp` is Q of the current
+  // hit at every node below the primary, and is filled in for the primary when it spawns a ray.
+  // (it lives in the upper half of `level` as a bfloat16, rounded up: a 97th vector register would cost the kernel a wave per SIMD)
+#define RT_LVL(L_) ((L_) & 255)
+#define RT_Q_GET(L_) __builtin_bit_cast(float, (uint32_t)(L_) & 0xffff0000u)
+#define RT_Q_SET(L_, Q_) (L_) = (int)(((uint32_t)(L_) & 255u) | ((__builtin_bit_cast(uint32_t, (float)(Q_)) + 0xffffu) & 0xffff0000u))
+#define RT_Q_FLAT 512.f
+#define RT_Q_OF(QP, T, INVR, C) fminf((4.f * (QP) + 2.f) * ((T) * (INVR)) * (1.f + ((T) * (INVR)) * __builtin_amdgcn_rcpf(fmaxf((C), 1e-30f))), 1e30f)
+#else
+#define RT_LVL(L_) (L_)
+#endif
   [[maybe_unused]] uint32_t tree_path = 1u;            // general kernel: position in the ray tree (root 1, reflect 2p, refract 2p+1)
 #if defined(RT_TESTING) && defined(RT_ABLATE_BOUNCE)
   uint32_t segs_left = L.segs ? 1 : 0;
@@ -799,7 +818,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         if (is_probe && probe_n < RT_PROBE_NODES) {
           double *q = L.probe + (size_t)(probe_n++) * RT_PROBE_WORDS;
           for (uint32_t z = 0; z < RT_PROBE_WORDS; z++) q[z] = 0.0;
-          q[0] = (double)(REFRACT ? tree_path : (1u << level)); q[1] = -1.0; q[2] = ht; q[9] = d.x; q[10] = d.y; q[11] = d.z;
+          q[0] = (double)(REFRACT ? tree_path : (1u << RT_LVL(level))); q[1] = -1.0; q[2] = ht; q[9] = d.x; q[10] = d.y; q[11] = d.z;
           q[17] = (double)segs_left; q[19] = p.x; q[20] = p.y; q[21] = p.z; q[23] = 1.0;
         }
 #endif
@@ -816,6 +835,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         const v3 n = mk((h.x - m.origin[0]) * inv_r, (h.y - m.origin[1]) * inv_r, (h.z - m.origin[2]) * inv_r);
 #endif
         const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
+#if !RT_STRICT
+        if (RT_LVL(level) != 0) { const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, (float)inv_r, __builtin_fabsf((float)dot(d, n))); RT_Q_SET(level, q_); }     // a bounced ray's hit (see above)
+#endif
         const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
         const double a4 = REFRACT ? m.albedo[4] : 0.0;
 
@@ -870,7 +892,13 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             RT_PIN();                                                                                             \
             iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
-            const double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol;                                 \
+            /* the tolerance grows with what this hit's normal error has been magnified by (qamp; a primary hit's Q from the camera) */ \
+            float q_here = RT_Q_GET(level);                                                                        \
+            if (RT_LVL(level) == 0) {                                                                             \
+              const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);   \
+              q_here = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, n)));       \
+            }                                                                                                     \
+            const double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol * (double)fmaxf(1.f, q_here * (1.f / RT_Q_FLAT));   \
             /* (a frequency of exactly 0 - stripes - makes the coordinate exactly 0 on every hit: it carries no error and decides nothing) */ \
             const bool zf = !(K->mark_flags & RT_MARK_ZERO);                                                       \
             const bool bu = (zf && (FU) == 0.0 && (XU) == 0.0) || (__builtin_fabs((XU) - __builtin_rint(XU)) >= tol);    \
@@ -927,7 +955,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px; sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
           }
           const unsigned long long pix = (unsigned long long)sy * (SS2 ? 2u * L.w : L.w) + sx;
-          const uint32_t path = REFRACT ? tree_path : (1u << level);
+          const uint32_t path = REFRACT ? tree_path : (1u << RT_LVL(level));
           double c = star_uniform((uint32_t)pix, (uint32_t)(pix >> 32), path);
           c = (c >= m.c[6]) ? 0.0 : c * m.c[7];     // main.js:137-138
           col[0] = col[1] = col[2] = c;
@@ -1211,7 +1239,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #ifdef RT_TESTING
         if (is_probe && probe_n < RT_PROBE_NODES) {
           double *q = L.probe + (size_t)(probe_n++) * RT_PROBE_WORDS;
-          q[0] = (double)(REFRACT ? tree_path : (1u << level)); q[1] = (double)hcode; q[2] = ht;
+          q[0] = (double)(REFRACT ? tree_path : (1u << RT_LVL(level))); q[1] = (double)hcode; q[2] = ht;
           q[3] = h.x; q[4] = h.y; q[5] = h.z; q[6] = n.x; q[7] = n.y; q[8] = n.z; q[9] = d.x; q[10] = d.y; q[11] = d.z;
           q[12] = col[0]; q[13] = col[1]; q[14] = col[2]; q[15] = diffuse; q[16] = specular; q[17] = (double)segs_left;
           q[18] = probe_li; q[19] = p.x; q[20] = p.y; q[21] = p.z; q[22] = (double)(go_r ? 1 : 0) + 2.0 * (go_f ? 1 : 0); q[23] = 1.0;
@@ -1236,6 +1264,14 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           double A[3], D[3];
 #pragma unroll
           for (int c = 0; c < 3; c++) { A[c] = col[c] * a0; D[c] = col[c] * diffuse + col[c] * specular; }
+#if !RT_STRICT
+          if (RT_LVL(level) == 0) {                                     // the primary hit spawns a ray: its Q (the camera is at hand; see above)
+            const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();
+            const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);
+            const float q_ = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, nq)));
+            RT_Q_SET(level, q_);
+          }
+#endif
           const bool via_f = REFRACT && !go_r;                          // the only child is the refraction ray
           if (REFRACT && go_r && go_f) {
             park &pk = parked[sp++];
@@ -1328,6 +1364,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             p = mk(pk.h[0], pk.h[1], pk.h[2]); d = mk(pk.f[0], pk.f[1], pk.f[2]);
             tree_path = 2u * pk.path + 1u; segs_left = pk.segs_left - 1u; level = pk.level + 1;
             hcode = pk.hcode;                          // the refraction ray starts on the parked node's sphere (bounce table)
+
             resumed = true;
           }
         }
