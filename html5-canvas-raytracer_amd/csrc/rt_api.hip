@@ -261,6 +261,7 @@ struct rt_scene_dev {
   std::mutex launch_mu;          // a product launch - its table (found or built), the trace launch, rt_retrace - is one step for the threads of this process
   bool needs_strict;             // the scene sits on an exact coincidence (below): every launch uses the strict kernel
   bool needs_strict_scene;       // ... whatever the camera (a light on a surface, a sphere without a radius, exotic checker frequencies)
+  bool unit_weights;             // every albedo and colour in [0, 1] (RT_MARK_WEIGHT)
   double flag_tol;               // RT_FLAG_T1 x the largest sampler frequency of the scene (texture width / height, checker frequencies): rt_device.h
 };
 
@@ -511,6 +512,13 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
     // product kernel's own error in a coordinate (~1e-16 x frequency) would shrink with it.  Such scenes take the strict kernel.
     if (fmaxq > 1048576.0) s->needs_strict_scene = true;
     s->flag_tol = RT_FLAG_T1 * fmaxq;
+    // (boundary marks) every albedo and colour within [0, 1]: then a node's colour moves the pixel by at most its accumulated weight
+    s->unit_weights = true;
+    for (uint32_t i = 0; i < hd->n_objects; i++) {
+      for (int c = 0; c < 5; c++) if (!(ob[i].albedo[c] >= 0.0 && ob[i].albedo[c] <= 1.0)) s->unit_weights = false;
+      for (int c = 0; c < 3; c++) if (!(ob[i].color[c] >= 0.0 && ob[i].color[c] <= 1.0)) s->unit_weights = false;
+      if (ob[i].sampler_kind == RT_SAMPLER_CHECKER) for (int c = 0; c < 6; c++) if (!(ob[i].checker_color[c / 3][c % 3] >= 0.0 && ob[i].checker_color[c / 3][c % 3] <= 1.0)) s->unit_weights = false;
+    }
   }
   memset(s->lights, 0, sizeof s->lights);
   if (hd->n_lights) memcpy(s->lights, base + hd->lights_offset, hd->n_lights * 24u);
@@ -1230,7 +1238,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   if (const char *fs = getenv("RT_FLAG_SCALE")) { L.flag_tol *= atof(fs); test_marks = true; }        // a wider boundary band, to exercise the second launch
   if (getenv("RT_MARK_ALL") || getenv("RT_EXACT_ALL") || no_fixup) test_marks = true;
 #endif
-  L.mark_flags = (RT_TEST_ENV("RT_MARK_ALL") ? RT_MARK_ALL : 0u) | (no_fixup ? RT_MARK_NEVER : 0u) | (RT_TEST_ENV("RT_TEST_MARK_STRIPES") ? RT_MARK_ZERO : 0u);
+  L.mark_flags = (RT_TEST_ENV("RT_MARK_ALL") ? RT_MARK_ALL : 0u) | (no_fixup ? RT_MARK_NEVER : 0u) | (RT_TEST_ENV("RT_TEST_MARK_STRIPES") ? RT_MARK_ZERO : 0u) | (s->unit_weights ? RT_MARK_WEIGHT : 0u);
   L.marks_cap = RT_MARKS_CAP;
   L.textures = s->d_texdesc;
   L.texel_base = db;

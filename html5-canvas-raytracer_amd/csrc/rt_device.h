@@ -131,6 +131,7 @@ struct rt_launch {
 #define RT_MARKS_CAP 8192u
 #define RT_MARK_ALL 4u               /* test build (RT_MARK_ALL): every hit with a texture / checker sampler is marked */
 #define RT_MARK_ZERO 16u             /* test build (RT_TEST_MARK_STRIPES): a coordinate with frequency 0 is marked like any exact integer (round 3's behaviour: overflows the list) */
+#define RT_MARK_WEIGHT 32u           /* every albedo and colour of the scene lies in [0, 1]: a sample whose accumulated weight is below a byte's worth is not marked */
 #define RT_MARK_NEVER 8u             /* test build (RT_NO_FIXUP): nothing is marked - the product kernel's own pixels */
 
 #define RT_PROBE_WORDS 24u

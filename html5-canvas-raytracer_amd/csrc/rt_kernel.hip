@@ -544,6 +544,14 @@ __device__ __forceinline__ void rt_mark_append(const rt_pixel &P) {
 }
 #endif
 
+#if !RT_STRICT
+// Q of a hit from its parent's (see trace_pixel: "How far this kernel's own rounding has been magnified"): x = t / r, c = |d.n|
+__device__ __forceinline__ float rt_q_of(float qp, float x, float c) {
+  const float ic = __builtin_amdgcn_rcpf(fmaxf(c, 1e-30f)), s = __builtin_sqrtf(fmaxf(0.f, 1.f - c * c));
+  return fminf(qp * (6.f * x + 1.f) * ic + x * (ic + s * (1.f + 0.5f * x * ic)), 1e30f);
+}
+#endif
+
 template <bool REFRACT, bool COUNT, bool GRID, bool SS2, bool ITEM = false>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull_lds, [[maybe_unused]] const rt_geom cull0, [[maybe_unused]] uint32_t lane,
@@ -580,21 +588,25 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
 #if !RT_STRICT
-  // How far this kernel's own rounding has been MAGNIFIED on the way to the current hit, as a bound on the hit's NORMAL error in units
-  // of 1.1e-16 (float: an estimate that only widens a tolerance).  A hit at distance t on a sphere of radius r met at incidence cosine
-  // c has its distance in error by ~eps t (1 + t / (r c)) - the near root t = tca - thc cancels when the ray grazes - on top of what the
-  // ray inherited, and its normal by that / r; the mirrored ray then carries ~4x the normal's error in its direction:
-  //     Q_hit = (4 Q_parent + 2) (t / r) (1 + t / (r c)),        Q = 0 at the camera.
-  // A primary hit on the floor has Q ~ 1e-2, on the reference's small spheres ~ 1e2 - 1e3; ONE grazing bounce off a sphere of radius
-  // 0.05 reaches 1e5 - 1e6 (profiles/r04_ab_log.md section 4: the adversarial soak's flipped pixel).  The samplers' boundary test
-  // scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below.  Updated per BOUNCE, not per node: `qamp` is Q of the current
-  // hit at every node below the primary, and is filled in for the primary when it spawns a ray.
+  // How far this kernel's own rounding has been MAGNIFIED on the way to the current hit: Q bounds the error of the hit's NORMAL in units
+  // of 1.1e-16 (a float, rounded up: an estimate that only widens a tolerance).  A ray with origin error P and direction error D meets
+  // a sphere of radius r after t at incidence cosine c (sine s): a sideways shift of the ray moves the hit along the surface by 1/c of
+  // it, so the normal inherits (P + t D) / (r c); the distance itself, t = tca - thc, is rounded to ~eps t (1 + t / (2 r c)) - the
+  // near root cancels when the ray grazes - and moves the hit along the ray, the normal by s / r of it; the mirrored (or refracted)
+  // ray leaves with D' <= 3 D + 4 Q and P' = r Q.  With D dominated by the previous normal's error:
+  //     Q_hit = Q_parent (6 t / r + 1) / c  +  (t / r) (1 / c + s (1 + t / (2 r c))),        Q = 0 at the camera.
+  // A primary hit on the floor has Q ~ 1e-2, on the reference's small spheres 1e1 - 1e3; every bounce off a sphere of radius r at
+  // distance t multiplies it by ~6 t / (r c), a grazing one by far more (profiles/r04_ab_log.md section 4: the adversarial soak's
+  // flipped pixel had ONE bounce).  The samplers' boundary test scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below;
+  // RT_Q_FLAT is a third of the Q at which the flat tolerance (2e-13 in u, v = Q 1.1e-16 / 2 pi) is exactly the bound.  Updated per
+  // BOUNCE, not per node: it is the Q of the current hit at every node below the primary, and is filled in for the primary when it
+  // spawns a ray.
   // (it lives in the upper half of `level` as a bfloat16, rounded up: a 97th vector register would cost the kernel a wave per SIMD)
 #define RT_LVL(L_) ((L_) & 255)
 #define RT_Q_GET(L_) __builtin_bit_cast(float, (uint32_t)(L_) & 0xffff0000u)
 #define RT_Q_SET(L_, Q_) (L_) = (int)(((uint32_t)(L_) & 255u) | ((__builtin_bit_cast(uint32_t, (float)(Q_)) + 0xffffu) & 0xffff0000u))
-#define RT_Q_FLAT 512.f
-#define RT_Q_OF(QP, T, INVR, C) fminf((4.f * (QP) + 2.f) * ((T) * (INVR)) * (1.f + ((T) * (INVR)) * __builtin_amdgcn_rcpf(fmaxf((C), 1e-30f))), 1e30f)
+#define RT_Q_FLAT 4096.f
+#define RT_Q_OF(QP, T, INVR, C) rt_q_of((QP), (T) * (INVR), (C))
 #else
 #define RT_LVL(L_) (L_)
 #endif
@@ -898,7 +910,15 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);   \
               q_here = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, n)));       \
             }                                                                                                     \
-            const double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol * (double)fmaxf(1.f, q_here * (1.f / RT_Q_FLAT));   \
+            double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol * (double)fmaxf(1.f, q_here * (1.f / RT_Q_FLAT));   \
+            /* ... and a sample whose colour cannot move the pixel by a byte is left alone: the pixel is F(x) = max(LO, min(HI, O + S x)) \
+               of this node's colour x (and of the parked nodes' maps above it), |dF| <= S |dx|, and a flipped texel / parity moves x by \
+               at most 2 when every albedo and colour of the scene lies in [0, 1] (RT_MARK_WEIGHT: the host's check) */              \
+            if ((K->mark_flags & (RT_MARK_WEIGHT | RT_MARK_ALL)) == RT_MARK_WEIGHT) {                              \
+              double S_ = map_valid ? acc[0] : 1.0;                                                               \
+              if constexpr (FOLD_FORWARD && REFRACT) for (int i_ = 0; i_ < sp; i_++) S_ *= (parked[i_].map_valid ? parked[i_].S : 1.0) * parked[i_].a3;   \
+              if (__builtin_fabs(S_) * 510.0 < 0.9) tol = -1.0;                                                    \
+            }                                                                                                     \
             /* (a frequency of exactly 0 - stripes - makes the coordinate exactly 0 on every hit: it carries no error and decides nothing) */ \
             const bool zf = !(K->mark_flags & RT_MARK_ZERO);                                                       \
             const bool bu = (zf && (FU) == 0.0 && (XU) == 0.0) || (__builtin_fabs((XU) - __builtin_rint(XU)) >= tol);    \
