@@ -1433,7 +1433,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       // The grid.  Count known: its items and the centre lines.  Not known yet (the first frame from a camera): the list may hold up
       // to RT_MARKS_CAP items or have overflowed - 256 workgroups (idle ones leave at once) walk an overflowed 3840x2160 frame at
       // ~130 samples per lane, once; from the next frame on the count is known (and an overflow takes the strict kernel above).
-      uint64_t n_wg = ((known ? known - 1u : 0u) + centre_items + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;
+      uint64_t n_wg = (((known ? known - 1u : 0u) + centre_items) * (ss2 ? 4u : 1u) + RT_WG_THREADS - 1) / RT_WG_THREADS + 2u;      // (supersample 2: a lane per sample)
       if (!known && n_wg < 256u) n_wg = 256u;
       if (retrace_all) n_wg = ((uint64_t)tiles->n_tiles * tiles->tile_rows * w * n_frames + RT_WG_THREADS - 1) / RT_WG_THREADS;
       if (n_wg > 8192u) n_wg = 8192u;

@@ -547,8 +547,8 @@ __device__ __forceinline__ void rt_mark_append(const rt_pixel &P) {
 #if !RT_STRICT
 // Q of a hit from its parent's (see trace_pixel: "How far this kernel's own rounding has been magnified"): x = t / r, c = |d.n|
 __device__ __forceinline__ float rt_q_of(float qp, float x, float c) {
-  const float ic = __builtin_amdgcn_rcpf(fmaxf(c, 1e-30f)), s = __builtin_sqrtf(fmaxf(0.f, 1.f - c * c));
-  return fminf(qp * (6.f * x + 1.f) * ic + x * (ic + s * (1.f + 0.5f * x * ic)), 1e30f);
+  const float ic = __builtin_amdgcn_rcpf(fmaxf(c, 1e-30f));                    // (s taken as 1: no square root on the way)
+  return fminf(ic * (qp * (6.f * x + 1.f) + x + 0.5f * x * x) + x, 1e30f);
 }
 #endif
 
@@ -600,7 +600,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   // flipped pixel had ONE bounce).  The samplers' boundary test scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below;
   // RT_Q_FLAT is a third of the Q at which the flat tolerance (2e-13 in u, v = Q 1.1e-16 / 2 pi) is exactly the bound.  Updated per
   // BOUNCE, not per node: it is the Q of the current hit at every node below the primary, and is filled in for the primary when it
-  // spawns a ray.
+  // spawns a ray (at the node's top, where the hit's distance is at hand).
   // (it lives in the upper half of `level` as a bfloat16, rounded up: a 97th vector register would cost the kernel a wave per SIMD)
 #define RT_LVL(L_) ((L_) & 255)
 #define RT_Q_GET(L_) __builtin_bit_cast(float, (uint32_t)(L_) & 0xffff0000u)
@@ -847,11 +847,15 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         const v3 n = mk((h.x - m.origin[0]) * inv_r, (h.y - m.origin[1]) * inv_r, (h.z - m.origin[2]) * inv_r);
 #endif
         const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
-#if !RT_STRICT
-        if (RT_LVL(level) != 0) { const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, (float)inv_r, __builtin_fabsf((float)dot(d, n))); RT_Q_SET(level, q_); }     // a bounced ray's hit (see above)
-#endif
         const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
         const double a4 = REFRACT ? m.albedo[4] : 0.0;
+#if !RT_STRICT
+        // Q of this hit (see above): for a bounced ray's hit, and for a primary hit that will spawn a ray (ht is at hand here)
+        if (RT_LVL(level) != 0 || ((a3 > 0.0 || a4 > 0.0) && segs_left > 1)) {
+          const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, (float)inv_r, __builtin_fabsf((float)dot(d, n)));
+          RT_Q_SET(level, q_);
+        }
+#endif
 
         // A8 sampler (main.js:320).  Pure, so it is evaluated here, before the lighting, where few values
         // are live: the OCML atan2/asin bodies are the register-pressure peak of the kernel.
@@ -906,7 +910,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
             /* the tolerance grows with what this hit's normal error has been magnified by (qamp; a primary hit's Q from the camera) */ \
             float q_here = RT_Q_GET(level);                                                                        \
-            if (RT_LVL(level) == 0) {                                                                             \
+            if (RT_LVL(level) == 0 && q_here == 0.f) {                  /* (a primary hit that spawns nothing: not filled in above) */ \
               const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);   \
               q_here = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, n)));       \
             }                                                                                                     \
@@ -1284,14 +1288,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           double A[3], D[3];
 #pragma unroll
           for (int c = 0; c < 3; c++) { A[c] = col[c] * a0; D[c] = col[c] * diffuse + col[c] * specular; }
-#if !RT_STRICT
-          if (RT_LVL(level) == 0) {                                     // the primary hit spawns a ray: its Q (the camera is at hand; see above)
-            const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();
-            const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);
-            const float q_ = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, nq)));
-            RT_Q_SET(level, q_);
-          }
-#endif
           const bool via_f = REFRACT && !go_r;                          // the only child is the refraction ray
           if (REFRACT && go_r && go_f) {
             park &pk = parked[sp++];
@@ -1693,7 +1689,12 @@ __global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
   const unsigned long long *list = (const unsigned long long *)(L.marks + 4);
   const rt_mtl *mtl = (const rt_mtl *)L.lds_image;                         // (HBM: nothing is staged here)
   const rt_texture_desc *tex = (const rt_texture_desc *)((const char *)L.lds_image + (size_t)L.n_objects * sizeof(rt_mtl));
-  for (unsigned long long i = (unsigned long long)blockIdx.x * RT_WG_THREADS + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * RT_WG_THREADS) {
+  // supersample 2: the four samples of an item's pixel in four adjacent lanes (a quad: the same item, the same control flow), their
+  // bytes summed across the quad - a marked sample of a many-sphere scene is a deep tree, and four of them one after the other were
+  // 0.35 ms of a 0.34 ms frame (profiles/r04_ab_log.md)
+  constexpr unsigned long long SUBS = SS2 ? 4ull : 1ull;
+  for (unsigned long long ii = (unsigned long long)blockIdx.x * RT_WG_THREADS + threadIdx.x; ii < total * SUBS; ii += (unsigned long long)gridDim.x * RT_WG_THREADS) {
+    const unsigned long long i = ii / SUBS;
     uint32_t px, frow, lrow, f;
     bool have_lrow = false;
     lrow = 0u;
@@ -1720,7 +1721,8 @@ __global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
     }
     if (px >= L.w || frow >= L.h || f >= L.n_frames) continue;
     uint32_t sum[3] = {0u, 0u, 0u};
-    for (uint32_t sub = 0; sub < (SS2 ? 4u : 1u); sub++) {
+    const uint32_t sub = (uint32_t)(ii % SUBS);
+    {
       const uint32_t sx = SS2 ? 2u * px + (sub & 1u) : px, sy = SS2 ? 2u * frow + (sub >> 1) : frow;
       // A1 primary ray (main.js:186-193), literally
       const double d0 = ((double)sx - L.proj_w) + 0.5, d1 = (L.proj_h - (double)sy) - 0.5, d2 = L.proj_d;
@@ -1735,7 +1737,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
       trace_pixel<REFRACT, false, false, SS2, true>(L, mtl, tex, nullptr, nullptr, rt_geom{0.0, 0.0, 0.0, 0.0}, 0u, 0.0, 0.0, 0.0, 0.0, o, ray, rgb, cnt, false, 0u, sx, sy);
       sum[0] += to_byte(rgb[0]); sum[1] += to_byte(rgb[1]); sum[2] += to_byte(rgb[2]);
     }
-    if (SS2) { sum[0] = (sum[0] + 2u) >> 2; sum[1] = (sum[1] + 2u) >> 2; sum[2] = (sum[2] + 2u) >> 2; }
+    if (SS2) {
+      uint32_t packed = sum[0] | (sum[1] << 10) | (sum[2] << 20);
+      packed += __shfl_xor(packed, 1);
+      packed += __shfl_xor(packed, 2);
+      sum[0] = ((packed & 1023u) + 2u) >> 2; sum[1] = (((packed >> 10) & 1023u) + 2u) >> 2; sum[2] = (((packed >> 20) & 1023u) + 2u) >> 2;
+      if (sub != 0u) continue;
+    }
     if (L.scatter) L.out_frames[f][(size_t)frow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
     else if (!L.rgb24) L.out[(size_t)f * L.frame_stride + (size_t)lrow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
     else {

@@ -1507,3 +1507,22 @@ def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
     assert ou.max_lsb(got, ou.c_oracle_render(blob, w, h))[0] <= 1
     if strict_scene:
         assert got == gpu_frame(lib, blob, w, h, STRICT)
+
+
+def test_adversarial_soak_seed_one_grazing_bounce_onto_a_fine_checker(lib):
+    """The pixel the 102 000-scene adversarial soak found (profiles/r04_ab_log.md section 4): a primary ray grazes a mirror of radius
+    ~0.1, its image lands 12.5 units away on the floor's checker at 100 000 squares per unit u, and the product kernel's own rounding,
+    magnified ~1e5 times on the way, put the sample on the other side of a boundary it was 1e-7 squares away from (13 LSB; round 3's
+    flat tolerance was 2e-8 there).  The tolerance now follows the magnification (rt_kernel.hip: the Q of a hit): marked, traced again
+    by the strict arithmetic, within 1 LSB."""
+    import soak_gpu_parity as soak
+    scene, w, h, tiles = soak.draw_adversarial(45084411)
+    rows = [8 * t + k for t in (tiles.tile_first, tiles.tile_first + tiles.tile_stride) for k in range(8)]
+    assert 3455 in rows
+    blob = rt_host.flatten_scene(scene)
+    want = ou.c_oracle_rows(blob, w, h, rows)
+    for flags in (FAST, STRICT):
+        got, st = gpu_tiles(lib, blob, w, h, (tiles.tile_rows, tiles.tile_first, tiles.tile_stride, tiles.n_tiles), flags, stats=True)
+        assert ou.max_lsb(got, want)[0] <= 1, flags
+        if flags == FAST:
+            assert st.exact_samples >= 1
