@@ -1090,11 +1090,7 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
       const uint32_t band_rows = po.n_tiles * po.tile_rows;
       const size_t frame_words = (size_t)band_rows * k * w * k;
       void *scratch = nullptr;
-#ifdef RT_AB_POOLED_SCRATCH     /* experiment only (profiles/r03_ab_log.md): the stream-ordered allocator that corrupted one frame in round 2 */
-      hipError_t e = hipMallocAsync(&scratch, frame_words * 4u * n_frames, stream);
-#else
       hipError_t e = hipMalloc(&scratch, frame_words * 4u * n_frames);
-#endif
       if (e != hipSuccess) return fail(RT_ERR_NOMEM, "supersample scratch (%zu bytes): %s", frame_words * 4u * n_frames, hipGetErrorString(e));
 #ifdef RT_TESTING
       (void)hipMemsetAsync(scratch, 0xA5, frame_words * 4u * n_frames, stream);      // test build: a sample nobody writes shows up as 0xA5, not as stale data
@@ -1116,12 +1112,8 @@ int render_supersampled(rt_scene_dev *s, uint32_t k, uint32_t w, uint32_t h, con
         e = hipGetLastError();
         if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "box filter launch: %s", hipGetErrorString(e));
       }
-#ifdef RT_AB_POOLED_SCRATCH
-      e = hipFreeAsync(scratch, stream);
-#else
       (void)hipStreamSynchronize(stream);            // (a 9x / 16x render: the allocation and this wait are noise beside it)
       e = hipFree(scratch);
-#endif
       if (rc) return rc;
       if (e != hipSuccess) return fail(RT_ERR_DEVICE, "supersample scratch release: %s", hipGetErrorString(e));
       if (stats) { agg.kernel_ms += st.kernel_ms; agg.rays += st.rays; agg.shadow_rays += st.shadow_rays; agg.sphere_tests += st.sphere_tests; }
@@ -1224,9 +1216,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
   };
   auto lds_for = [&](bool strict) {
-#ifdef RT_AB_LDS_SPHERES
-    if (!strict) return s->lds_bytes + lds_pad + (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u + s->hd.n_objects * 32u * (2u + s->hd.n_lights);     // EXPERIMENT: + the geometry tables
-#endif
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };

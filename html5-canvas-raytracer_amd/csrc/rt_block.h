@@ -27,7 +27,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RT_HD __host__ __device__
 #else
 #define RT_HD

@@ -267,8 +267,6 @@ __device__ __forceinline__ double fd_asin(double x) {
 }
 // atan2(y, x) and asin(w) of one surface normal (the two halves of main.js:446-447 / :127-128)
 __device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) { *at = fd_atan2(y, x); *as = fd_asin(w); }
-#elif defined(RT_TESTING) && defined(RT_AB_OCML_TRIG)
-__device__ __forceinline__ void rt_atan2_asin(double y, double x, double w, double *at, double *as) { *at = atan2(y, x); *as = asin(w); }
 #else
 __device__ __forceinline__ double rt_fma_k(double a, double b, double k) {     // a*b + k, k wave-uniform: v_fma_f64 v, v, v, s[..]
   double r;
@@ -521,14 +519,6 @@ __device__ __forceinline__ const rt_launch __attribute__((address_space(4))) *rt
   asm volatile("" : "+s"(K));
   return K;
 }
-#ifdef RT_AB_LDS_SPHERES
-// EXPERIMENT: where the prologue staged the geometry tables in LDS (behind the LDS image and the fold state)
-template <bool REFRACT, bool GRID>
-__device__ __forceinline__ const double *rt_lds_tables(const rt_launch &L) {
-  extern __shared__ double lds_raw[];
-  return lds_raw + L.n_objects * ((uint32_t)(sizeof(rt_mtl) / 8) + (GRID ? 0u : 4u)) + 32u + (REFRACT ? 13u : 10u) * RT_WG_THREADS;
-}
-#endif
 // Append this work-item's sample to the launch's mark list (the cold end of the samplers' boundary test, a handful of samples per frame): entry = sample x |
 // sample y << 20 | frame of the batch << 40; the counter of THIS launch is marks[marks_slot] (rt_api.hip alternates two, so that
 // rt_retrace can clear the next launch's while it reads its own); beyond the list's capacity only the count grows and rt_retrace
@@ -580,10 +570,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   [[maybe_unused]] frame<REFRACT> stack[FOLD_FORWARD ? 1 : RT_MAX_SEGS];
   // product general kernel: nodes with BOTH a reflection and a refraction child are parked here while their
   // reflection subtree is traced (everything else needs no stack)
-#ifndef RT_AB_PARK_DEPTH
-#define RT_AB_PARK_DEPTH RT_MAX_SEGS
-#endif
-  [[maybe_unused]] park parked[(FOLD_FORWARD && REFRACT) ? RT_AB_PARK_DEPTH : 1];
+  [[maybe_unused]] park parked[(FOLD_FORWARD && REFRACT) ? RT_MAX_SEGS : 1];
   [[maybe_unused]] int sp = 0;
   [[maybe_unused]] bool map_valid = false;             // false: the accumulated map F is the identity
   int level = 0;
@@ -651,18 +638,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
       // 32-bit byte offset (at most 256 spheres x 32 bytes, times at most 16 lights in the light-anchored table): base +
       // zext(offset) lets the scalar load take its offset from an SGPR (s_load_dwordx8 s[..], s[base], s_off) instead of
       // a 64-bit address computation per load (+0.8 % on the headline)
-#if !RT_STRICT && defined(RT_AB_LDS_SPHERES)
-      // EXPERIMENT (profiles/r03_ab_log.md; north_star: "sphere/light list staged in LDS"): the three geometry tables are staged into LDS
-      // behind the fold state by the kernel's prologue and every record is a broadcast LDS read into VECTOR registers
-      [[maybe_unused]] const rt_geom *const RT_LDS_geom = (const rt_geom *)rt_lds_tables<REFRACT, GRID>(L);
-      [[maybe_unused]] const rt_geom *const RT_LDS_gl = RT_LDS_geom + N;
-      [[maybe_unused]] const rt_geom *const RT_LDS_ga = RT_LDS_geom + (size_t)N * (1u + NL);
-#define RT_LOAD(TAB, I) (RT_LDS_##TAB[(uint32_t)(I)])
-#define RT_LOAD_PAIR(TAB, I) (rt_geom_pair{RT_LDS_##TAB[(uint32_t)(I)], RT_LDS_##TAB[(uint32_t)(I) + 1u]})
-#else
 #define RT_LOAD(TAB, I) rt_load_geom32((TAB), (uint32_t)(I))
 #define RT_LOAD_PAIR(TAB, I) rt_load_geom_pair32((TAB), (uint32_t)(I))
-#endif
       // Both loops are unrolled by two by hand (the pinned branches make them convergent, which rules out
       // the compiler's runtime unrolling); a pair's two records come with ONE s_load_dwordx16 (rt_load_geom_pair32).
   if (segs_left != 0) {
@@ -820,11 +797,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
 #else
         // (read where it is used, from the kernarg segment: six scalar registers less across the whole loop)
-#ifdef RT_AB_HOT_MISS
-        ret[0] = L.miss_color[0]; ret[1] = L.miss_color[1]; ret[2] = L.miss_color[2];
-#else
         { const rt_launch __attribute__((address_space(4))) *K = rt_cold_args(); ret[0] = K->miss_color[0]; ret[1] = K->miss_color[1]; ret[2] = K->miss_color[2]; }
-#endif
 #endif
 #ifdef RT_TESTING
         if (is_probe && probe_n < RT_PROBE_NODES) {
@@ -904,7 +877,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           uint32_t iu = __builtin_amdgcn_alignbit((uint32_t)(su >> 32), (uint32_t)su, 20u) ^ 0x80000000u;       /* floor(x) for x in [0, 2^31) ... */ \
           uint32_t iv = __builtin_amdgcn_alignbit((uint32_t)(sv >> 32), (uint32_t)sv, 20u) ^ 0x80000000u;       \
           /* ... unless the fraction is within 2^-20 of an integer <=> the 20 fraction bits are 0xfffff, 0 or 1 (NaN, infinity: 0) */ \
-          if (RT_AB_MARK_COND(min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u)) {           \
+          if ((min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u)) {           \
             RT_PIN();                                                                                             \
             iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
@@ -933,11 +906,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               rt_mark_append<SS2>(rt_pixel_of<SS2>(L, t3));                                                        \
             }                                                                                                     \
           }
-#ifdef RT_AB_NO_MARK_TEST     /* timing experiments only (profiles/ab_build.sh) */
-#define RT_AB_MARK_COND(C) false
-#else
-#define RT_AB_MARK_COND(C) (C)
-#endif
         if (kind == RT_SAMPLER_TEXTURE) {
           double t_at, t_as;
           rt_atan2_asin(-n.z, -n.x, -n.y, &t_at, &t_as);
@@ -949,11 +917,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           // the index comes out of the fixed-point sum (u, v in [0, 1]; widths and heights <= 16384)
           RT_XY_INDEX(xu, xv, 1.0, 1.0)
           const uint32_t xi = min(iu, td.width - 1u), yi = min(iv, td.height - 1u);   // memory safety only; u,v <= 1
-#ifdef RT_AB_HOT_TEXEL
-          const uint32_t texel = *(const uint32_t *)(L.texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
-#else
           const uint32_t texel = *(const uint32_t *)(rt_cold_args()->texel_base + td.texels_offset + ((size_t)yi * td.width + xi) * 4u);
-#endif
           col[0] = RT_DIV_CONST((double)(texel & 255u), 255.0); col[1] = RT_DIV_CONST((double)((texel >> 8) & 255u), 255.0);
           col[2] = RT_DIV_CONST((double)((texel >> 16) & 255u), 255.0);
         } else if (kind == RT_SAMPLER_CHECKER) {
@@ -966,7 +930,6 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           const int c = (int)((iu ^ iv) & 1u);                       // the parity of floor(x) = ToInt32(x) & 1 for x in [0, 2^31)
           col[0] = m.c[3 * c]; col[1] = m.c[3 * c + 1]; col[2] = m.c[3 * c + 2];
 #undef RT_XY_INDEX
-#undef RT_AB_MARK_COND
 #endif
         } else if (kind == RT_SAMPLER_STARS) {
           // the sample's index in the FRAME (not in this call's tiles), recomputed from the work-item id so that it
@@ -1003,11 +966,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #if RT_STRICT
           double li = L.light_intensity;                               // shared across lights (q2)
 #else
-#ifdef RT_AB_HOT_LI
-          double li = L.light_intensity;
-#else
           double li = rt_cold_args()->light_intensity;                 // shared across lights (q2); read where it is used (two scalar registers less across the loop)
-#endif
 #endif
 #if !RT_STRICT
           [[maybe_unused]] uint32_t smask = ~0u;
@@ -1482,9 +1441,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
   // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last
   // entry are zero (rt_tables_gpu.hip)
-#ifndef RT_AB_NO_ZERO_EXIT   /* (defined: timing experiment) */
   if (P0.rows_valid == 0u) return;
-#endif
   // (RT_FLAG_NO_SKY / RT_FLAG_SKY_ONLY - a frame assembled from several GPUs' tiles: the OWNER fills the sky blocks of the whole frame,
   // the others do not send them over the links - are launch tables of their own, without the entries the launch leaves out: this
   // kernel knows nothing of it.  As a test of the launch record here it cost the headline 1.5 %.)
@@ -1539,13 +1496,6 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     if (tid < image_words) lds_raw[tid] = stage0;
     for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   }
-#if !RT_STRICT && defined(RT_AB_LDS_SPHERES)
-  {
-    double *tabs = (double *)rt_lds_tables<REFRACT, GRID>(L);
-    const uint32_t w1 = L.n_objects * 4u * (1u + L.n_lights), w2 = L.n_objects * 4u;          // [plain | lights] from L.geom, then the camera-anchored table
-    for (uint32_t k = tid; k < w1 + w2; k += RT_WG_THREADS) tabs[k] = k < w1 ? ((const double *)L.geom)[k] : ((const double *)L.geom_cam)[k - w1];
-  }
-#endif
   __syncthreads();
 
   // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)

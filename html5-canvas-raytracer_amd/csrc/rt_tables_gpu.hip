@@ -85,7 +85,6 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
   const uint32_t sub = threadIdx.x % SUB;
   for (uint32_t x = threadIdx.x / SUB; x < tiles_x; x += WG_ROWS / SUB) {
     uint32_t touched = 1u, cands = 0u, smask = 0xffffffffu, extra = 0u;
-#ifndef RT_TAB_NO_STMT   /* (defined: timing experiments, profiles/ab_build.sh) */
     if (P.flags & RT_TABLE_GEOMETRY) {
       const rt_cone K = rt_block_cone(P, x, y);
       uint64_t cand[4] = {0ull, 0ull, 0ull, 0ull};
@@ -124,14 +123,9 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
         }
       }
     }
-#endif
     if (sub != 0u) continue;
-#ifdef RT_TAB_NO_COST
-    const uint32_t cost = 1u + (x & 3u);
-#else
     uint32_t cost = rank ? rt_block_cost(P, rects, x, y) + extra : 1u;
     cost = cost < RT_COST_MAX ? cost : RT_COST_MAX;
-#endif
     const size_t at = (size_t)y * tiles_x + x;
     T.blk[3u * at] = cost; T.blk[3u * at + 1u] = smask; T.blk[3u * at + 2u] = cands;
     l_touched[x] = (!sky || touched) ? 1u : 0u;
@@ -159,9 +153,7 @@ __global__ void __launch_bounds__(WG_ROWS) rt_table_rows(const rt_table_dev T, u
     const uint32_t key = l_key[x];
     if (!key) continue;
     uint32_t before = 0u;                                                                  // entries of the same cost to the left: the grid's order among equals
-#ifndef RT_TAB_NO_RANKLOOP
     for (uint32_t i = 0; i < x; i++) before += (l_key[i] == key) ? 1u : 0u;
-#endif
     T.rank_in_row[(size_t)y * tiles_x + x] = before;
   }
   for (uint32_t c = threadIdx.x; c < bins; c += WG_ROWS) T.row_hist[(size_t)y * bins + c] = l_hist[c];
