@@ -240,11 +240,12 @@ struct rt_scene_dev {
   // behind all of T's arrays; `n_blocks` workgroups are launched until the host has seen the number of entries the build published
   // (`known`: generation << 32 | entries + 1, a pinned host word), from then on exactly that many.
   struct order_entry {
-    uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; bool ranked, sky, masks, cands; uint32_t part;
+    uint32_t w, h, ss, tile_rows, tile_first, tile_stride, n_tiles; int ranked; bool sky, masks, cands; uint32_t part;     // ranked: 0 grid order, 1 ranked when large enough, 2 always (a compact band's launch)
     uint64_t cam_gen; uint32_t n_blocks; volatile unsigned long long *known; hipStream_t built_on; hipEvent_t built;
     bool shared;                   // launched with on a stream other than the one it was built on
     // two tables, like the camera blocks: generation g's is Tb[g & 1] (the next camera's is built while this one's is still read)
     rt_table_dev Tb[2]; uint8_t *d_blockb[2]; size_t hist_wordsb[2];
+    uint32_t cost_bins;            // of the current build (rt_retrace of a compact launch)
     uint64_t used_gen;             // the last camera generation a launch used it with: a move rebuilds the tables in use ahead of the next render
   };
   std::vector<order_entry> orders;
@@ -882,6 +883,7 @@ bool build_table(rt_scene_dev *s, int found, const rt_tiles *tiles, uint32_t til
     (void)hipDeviceSynchronize();
   }
   e.n_blocks = n;
+  e.cost_bins = P.cost_bins;
   e.cam_gen = s->cam_gen;
   T.known_tag = (uint32_t)s->cam_gen;
   e.built_on = stream; e.shared = false;
@@ -909,7 +911,7 @@ bool build_table(rt_scene_dev *s, int found, const rt_tiles *tiles, uint32_t til
 // scene's side stream, or by an earlier launch - or built now on `stream`.  Called with the scene's launch_mu held.  Returns the
 // entry's index, or -1 (rt_last_error says why).
 int dispatch_order(rt_scene_dev *s, uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile,
-                   double proj_w, double proj_h, double proj_d, bool ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t sky_part, hipStream_t stream) {
+                   double proj_w, double proj_h, double proj_d, int ranked, bool mark_sky, bool shadow_masks, bool name_candidates, uint32_t sky_part, hipStream_t stream) {
   // sky_part: 0 every entry; 1 (RT_FLAG_NO_SKY) a table without the sky runs; 2 (RT_FLAG_SKY_ONLY) a table of nothing else - tables of
   // their own, so that the trace kernel knows nothing of it (a test of the launch record in its prologue cost the headline 1.5 %)
   int found = -1;
@@ -1145,6 +1147,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   if ((flags & RT_FLAG_RGB24) && (w & 3u)) return fail(RT_ERR_INVALID, "RT_FLAG_RGB24 needs a frame width that is a multiple of 4 (got %u)", w);
   if ((flags & (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY)) == (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY) || ((flags & (RT_FLAG_NO_SKY | RT_FLAG_SKY_ONLY)) && (flags & RT_FLAG_COUNT)))
     return fail(RT_ERR_INVALID, "RT_FLAG_NO_SKY and RT_FLAG_SKY_ONLY exclude each other and RT_FLAG_COUNT");
+  if ((flags & RT_FLAG_COMPACT) && ((flags & (RT_FLAG_RGB24 | RT_FLAG_NO_SKY | RT_FLAG_COUNT | RT_FLAG_STRICT_FP)) != (RT_FLAG_RGB24 | RT_FLAG_NO_SKY) || d_frames))
+    return fail(RT_ERR_INVALID, "RT_FLAG_COMPACT goes with RT_FLAG_RGB24 | RT_FLAG_NO_SKY into a band (no counting, no strict kernel, no scatter)");
   int rc = ensure_device(s->device);
   if (rc) return rc;
   device_state &D = G.dev[s->device];
@@ -1172,6 +1176,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   // rt_scene_upload): only the operation-for-operation kernel reproduces those.
   const bool no_fixup = RT_TEST_ENV("RT_NO_FIXUP") != nullptr;                 // test build: the product kernel's own pixels everywhere (read per call)
   const bool strict_main = (flags & RT_FLAG_STRICT_FP) != 0 || (s->needs_strict && !no_fixup);
+  const bool compact = (flags & RT_FLAG_COMPACT) != 0;
+  if (compact && (strict_main || ss > 2u)) return fail(RT_ERR_UNSUPPORTED, "RT_FLAG_COMPACT: this scene is rendered by the strict kernel (or supersampled 3x3 / 4x4), which knows no launch table: send plain bands");
   const uint8_t *db = (const uint8_t *)s->d_blob;
   static const bool no_grid = RT_TEST_ENV("RT_NO_SHADOW_GRID") != nullptr;     // A/B switches (test build only)
   static const bool no_bounce = RT_TEST_ENV("RT_NO_BOUNCE_TABLE") != nullptr;
@@ -1253,6 +1259,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   L.n_frames = n_frames;
   L.frame_stride = frame_stride_bytes / 4u;
   L.rgb24 = (flags & RT_FLAG_RGB24) ? 1u : 0u;
+  L.compact = compact ? 1u : 0u;
   L.scatter = d_frames ? 1u : 0u;
   if (d_frames) for (uint32_t f = 0; f < n_frames; f++) L.out_frames[f] = (uint32_t *)d_frames[f];
   for (int c = 0; c < 3; c++) L.cam_axis_sum[c] = hd.cam_axis_x[c] + hd.cam_axis_y[c] + hd.cam_axis_z[c];
@@ -1326,7 +1333,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // (a table of nothing but sky runs is read by workgroups that store a constant: neither masks nor candidates)
     const bool shadow_masks = !count && !no_shadow_masks && masks_pay && sky_part != 2u && (s->enclosing == ~0u || s->enclosing_flat);
     const bool name_candidates = !count && !no_shadow_masks && sky_part != 2u;
-    const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, !count && !no_order, mark_sky,
+    const int oi = dispatch_order(s, w, h, ss2 ? 2u : 1u, tiles, L.tiles_x, L.rb_per_tile, L.proj_w, L.proj_h, L.proj_d, compact ? 2 : ((!count && !no_order) ? 1 : 0), mark_sky,
                                   shadow_masks, name_candidates, sky_part, stream);
     if (oi < 0) return RT_ERR_DEVICE;
     rt_scene_dev::order_entry &oe = s->orders[oi];
@@ -1358,7 +1365,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // A frame KNOWN to mark more samples than the list holds (a legal scene can: every hit of a sphere whose sampler coordinate is
     // an exact integer everywhere) would be traced twice in full, product kernel then rt_retrace over every sample: the strict
     // kernel renders it once instead, the same bytes (the count stays known: nothing republishes it for this camera).
-    const bool overflow_known = known != 0u && known - 1u > RT_MARKS_CAP && !count;
+    const bool overflow_known = known != 0u && known - 1u > RT_MARKS_CAP && !count && !compact;
     if (overflow_known) {
       if (!(flags & RT_FLAG_SKY_ONLY)) {              // (as every strict launch: a NO_SKY call stores every pixel, a SKY_ONLY call none)
         rt_launch S = L;
@@ -1415,6 +1422,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     const bool need = !no_fixup && !(flags & RT_FLAG_SKY_ONLY) && (known != 1u || centre_items != 0 || retrace_all);     // (a sky-only launch traces nothing; the centre lines belong to the calls that trace)
     if (err == 0 && need) {
       bind_kernel(F, true);                             // the scene in its own order, every sphere in the loops, the reference's own miss colour
+      if (compact) {                                    // where a sample's block sits in the compact band: from the table's own arrays
+        const rt_table_dev &T = oe.Tb[s->cam_gen & 1u];
+        F.tb_item = T.item; F.tb_rank_in_row = T.rank_in_row; F.tb_row_hist = T.row_hist; F.tb_bin_start = T.bin_start; F.tb_bins = oe.cost_bins;
+      }
       F.marks_known = test_marks ? nullptr : (unsigned long long *)ms->h_known;
       F.known_tag = (uint32_t)s->cam_gen;
       F.retrace_all = retrace_all ? 1u : 0u;
@@ -1468,6 +1479,88 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   return RT_OK;
 }
 }  // namespace
+
+// ------------------------------------------------------------------------------------ compact bands (RT_FLAG_COMPACT)
+namespace {
+// the launch table a compact launch over `tiles` uses (found, or built now on `stream`), under launch_mu; -1: rt_last_error
+int compact_table(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, hipStream_t stream, uint32_t *rows_per_wg_out) {
+  if (!s || !tiles) { fail(RT_ERR_INVALID, "NULL scene or tiles"); return -1; }
+  if (w == 0 || h == 0 || w > 65536 || h > 65536 || (w & 3u) || tiles->tile_rows == 0 || tiles->tile_stride == 0 || tiles->n_tiles == 0) { fail(RT_ERR_INVALID, "compact band: bad frame size or tile set (w must be a multiple of 4)"); return -1; }
+  const uint32_t ss = s->hd.supersample;
+  if (ss > 2u || s->needs_strict) { fail(RT_ERR_UNSUPPORTED, "compact bands: this scene is rendered by the strict kernel (or supersampled 3x3 / 4x4): send plain bands"); return -1; }
+  const bool ss2 = ss == 2u;
+  const uint32_t rows_per_wg = ss2 ? 2u : RT_TILE_H;
+  const uint32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W, rb_per_tile = (tiles->tile_rows + rows_per_wg - 1) / rows_per_wg;
+  const double sw = ss2 ? 2.0 * w : (double)w, sh = ss2 ? 2.0 * h : (double)h;                    // (render_batch_impl's expressions: the same bits)
+  const double projA = s->hd.fov_deg * M_PI / 180.0, pw = sw / 2.0, ph = sh / 2.0, pd = pw / tan(projA / 2.0);
+  if (behind_the_camera(s, stream)) return -1;
+  // the product launch's own choices (render_batch_impl): sky marks for a constant background; candidates; masks do not matter for the
+  // ORDER of the blocks - a table with and one without them list the same blocks at the same places
+  const bool sky_fast = (s->enclosing_flat && s->sky_const) || (s->enclosing == ~0u && s->hd.segs > 0);
+  const uint32_t n_loop = s->hd.n_objects - (s->enclosing != ~0u ? 1u : 0u);
+  const bool masks = (n_loop <= 16u) && (s->enclosing == ~0u || s->enclosing_flat);
+  *rows_per_wg_out = rows_per_wg;
+  return dispatch_order(s, w, h, ss, tiles, tiles_x, rb_per_tile, pw, ph, pd, 2, sky_fast, masks, true, 1u, stream);
+}
+
+struct rt_expand_launch { const uint32_t *entries; uint32_t n8, n_blocks, w, rows_per_wg; const uint8_t *src; uint32_t *dst; };
+// one workgroup of 256 per entry: the block's 32 x RH pixels (RGB24, row by row) to their place in the RGBA8 frame
+__global__ void __launch_bounds__(256) rt_compact_expand_kernel(const rt_expand_launch E) {
+  const uint32_t b = blockIdx.x;
+  const uint4 e = ((const uint4 *)E.entries)[(size_t)(b & 7u) * E.n8 + (b >> 3)];
+  const uint32_t tile_x = e.x & 2047u, rows_valid = (e.x >> 11) & 15u, frow0 = e.x >> 15;
+  if (rows_valid == 0u || (e.y >> 31)) return;                     // (no entry, or a sky run: not part of a compact band)
+  const uint32_t r = threadIdx.x >> 5, i = threadIdx.x & 31u, px = tile_x * RT_TILE_W + i;
+  if (r >= rows_valid || r >= E.rows_per_wg || px >= E.w) return;
+  const uint8_t *p = E.src + (size_t)b * (RT_TILE_W * 3u * E.rows_per_wg) + ((size_t)r * RT_TILE_W + i) * 3u;
+  E.dst[(size_t)(frow0 + r) * E.w + px] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+}
+}  // namespace
+
+extern "C" int rt_compact_count(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, void *hip_stream, uint32_t *n_blocks, uint32_t *block_bytes) {
+  if (!n_blocks || !block_bytes) return fail(RT_ERR_INVALID, "rt_compact_count: NULL argument");
+  int rc = s ? ensure_device(s->device) : RT_ERR_INVALID;
+  if (rc) return rc == RT_ERR_INVALID ? fail(RT_ERR_INVALID, "NULL scene") : rc;
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[s->device].stream;
+  uint32_t rows_per_wg = 0, header[4];
+  const uint32_t *d_header = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    const int oi = compact_table(s, w, h, tiles, stream, &rows_per_wg);
+    if (oi < 0) return (strstr(rt_last_error(), "strict kernel") != nullptr) ? RT_ERR_UNSUPPORTED : RT_ERR_DEVICE;
+    d_header = s->orders[oi].Tb[s->cam_gen & 1u].header;
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemcpy(header, d_header, sizeof header, hipMemcpyDeviceToHost));
+  *n_blocks = header[2];                                             // the entries in front of the sky runs' class: a ranked table's non-sky blocks
+  *block_bytes = RT_TILE_W * 3u * rows_per_wg;
+  return RT_OK;
+}
+
+extern "C" int rt_compact_expand_device(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *tiles, const void *d_compact, void *d_frame, void *hip_stream) {
+  if (!d_compact || !d_frame || ((uintptr_t)d_frame & 3u)) return fail(RT_ERR_INVALID, "rt_compact_expand_device: NULL or unaligned buffer");
+  int rc = s ? ensure_device(s->device) : RT_ERR_INVALID;
+  if (rc) return rc == RT_ERR_INVALID ? fail(RT_ERR_INVALID, "NULL scene") : rc;
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : G.dev[s->device].stream;
+  rt_expand_launch E;
+  uint32_t grid = 0;
+  {
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    uint32_t rows_per_wg = 0;
+    const int oi = compact_table(s, w, h, tiles, stream, &rows_per_wg);
+    if (oi < 0) return (strstr(rt_last_error(), "strict kernel") != nullptr) ? RT_ERR_UNSUPPORTED : RT_ERR_DEVICE;
+    const rt_scene_dev::order_entry &oe = s->orders[oi];
+    E.entries = oe.Tb[s->cam_gen & 1u].entries; E.n8 = (oe.n_blocks + 7u) / 8u; E.n_blocks = oe.n_blocks; E.w = w; E.rows_per_wg = rows_per_wg;
+    E.src = (const uint8_t *)d_compact; E.dst = (uint32_t *)d_frame;
+    const uint32_t n_known = known_value(oe.known, s->cam_gen);
+    grid = n_known ? n_known - 1u : oe.n_blocks;                     // (workgroups behind the last entry read a zero slot and leave)
+    if (s->any_launch && s->last_stream != stream) s->several_streams = true;
+    s->last_stream = stream; s->any_launch = true; s->launched_since_move = true;
+  }
+  if (grid) hipLaunchKernelGGL(rt_compact_expand_kernel, dim3(grid), dim3(256), 0, stream, E);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
 
 // ------------------------------------------------------------------------------------ sharing memory between the ranks of a node
 extern "C" int rt_ipc_export(int device, const void *d_ptr, void *handle_out) {

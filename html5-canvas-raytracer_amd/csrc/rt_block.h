@@ -88,7 +88,7 @@ RT_HD inline double rt_block_row0(const rt_table_params &P, uint32_t y) {
 
 RT_HD inline uint32_t rt_block_cost(const rt_table_params &P, const rt_cost_rect *rects, uint32_t x, uint32_t y) {
   const double row0 = rt_block_row0(P, y);
-  uint32_t cost = 1u;
+  uint32_t cost = 2u;                                  // (sky runs are 1: the last class of a ranked table is theirs alone - a compact band's blocks are then 0 .. n - 1)
   for (uint32_t j = 0; j < P.n_rects; j++) {
     const rt_cost_rect &r = rects[j];
     if (x < r.tx0 || x > r.tx1) continue;

@@ -83,7 +83,7 @@ struct rt_launch {
   uint32_t enclosing_flat;           // that sphere neither lights nor spawns rays and its colour ignores the hit point: its test is skipped
   uint32_t cull_in_lds;              // 1: few spheres (no shadow grid, no bounce table): the cull rectangles are part of the LDS image, the product launch takes the few-sphere kernel; 0: the many-sphere kernel, every lane fetches its sphere's rectangle from `cull` (HBM / L2)
   uint32_t rgb24;                    // RT_FLAG_RGB24: rows are w*3 bytes (R,G,B), no alpha byte; w % 4 == 0
-  uint32_t reserved_sky;             // (keeps the record's layout)
+  uint32_t compact;                  // RT_FLAG_COMPACT (with rgb24): block b of the launch is stored whole at out + b * block bytes (a compact band for a collective)
   uint32_t scatter;                  // rt_render_scatter_device: frame f goes to out_frames[f] (possibly another GPU's memory,
                                      // peer-mapped), its rows in FRAME order; `out` and frame_stride are unused
   uint32_t *out_frames[RT_MAX_SCATTER];
@@ -110,6 +110,9 @@ struct rt_launch {
   uint32_t known_tag;                // (the camera generation the frame is rendered with)
   uint32_t centre_row, centre_col;   // frame row / column of the odd sample grid's centre within this call's tiles, or ~0u
   uint32_t retrace_all;              // test build (RT_EXACT_ALL): every sample of the call
+  // ... of a compact launch: the table's arrays, from which a sample's block finds its place in the band (rt_tables_gpu.hip: rt_table_emit's arithmetic)
+  const uint32_t *tb_item, *tb_rank_in_row, *tb_row_hist, *tb_bin_start;
+  uint32_t tb_bins, tb_pad;
 #ifdef RT_WAVE_LOG
   // measurement builds only (profiles/ab_build.sh ... "-DRT_WAVE_LOG" hybrid; profiles/wave_timeline.py): per wave of the product launch
   // four words {s_memrealtime at entry, at exit, HW_ID | XCC_ID << 32, workgroup}; NULL = off

@@ -1591,7 +1591,10 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #else
       const bool row_ok = P1.trow < P1.rows_valid;
 #endif
-      if (row_ok && j < in_row && P1.sub == 0u) out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
+      if (!(row_ok && j < in_row && P1.sub == 0u)) continue;
+      // RT_FLAG_COMPACT: the block whole, at its place in the LAUNCH (a compact band: rows of 32 pixels = 24 words, 8 - or 2 - of them)
+      if (L.compact) out[(size_t)blockIdx.x * (RT_TILE_W * 3u / 4u * (SS2 ? 2u : RT_TILE_H)) + P1.trow * (RT_TILE_W * 3u / 4u) + (((tid2 >> 6) * 8u) >> 2) * 3u + j] = word;
+      else out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
     }
   }
 
@@ -1696,8 +1699,17 @@ __global__ void __launch_bounds__(RT_WG_THREADS) rt_retrace(const rt_launch L) {
     }
     if (L.scatter) L.out_frames[f][(size_t)frow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
     else if (!L.rgb24) L.out[(size_t)f * L.frame_stride + (size_t)lrow * L.w + px] = sum[0] | (sum[1] << 8) | (sum[2] << 16) | 0xff000000u;
-    else {
+    else if (!L.compact) {
       uint8_t *o8 = (uint8_t *)(L.out + (size_t)f * L.frame_stride) + ((size_t)lrow * L.w + px) * 3u;
+      o8[0] = (uint8_t)sum[0]; o8[1] = (uint8_t)sum[1]; o8[2] = (uint8_t)sum[2];
+    } else {
+      // a compact band: the sample's block is workgroup b of the product launch - class start + entries of its class in the rows
+      // above + its rank in the row (rt_tables_gpu.hip: rt_table_emit) -, its pixel row r, column i of the block's 32 x RH pixels
+      const uint32_t RH = SS2 ? 2u : RT_TILE_H, y = lrow / RH, x = px / RT_TILE_W, at = y * L.tiles_x + x;
+      const uint32_t it = L.tb_item[at];
+      if (!it || (it >> 16)) continue;                     // (inside a run of sky blocks: a compact band holds none)
+      const uint32_t bin = (it & 0xffffu) - 1u, b = L.tb_bin_start[bin] + L.tb_row_hist[(size_t)y * L.tb_bins + bin] + L.tb_rank_in_row[at];
+      uint8_t *o8 = (uint8_t *)(L.out + (size_t)f * L.frame_stride) + (size_t)b * (RT_TILE_W * 3u * RH) + ((size_t)(lrow - y * RH) * RT_TILE_W + (px - x * RT_TILE_W)) * 3u;
       o8[0] = (uint8_t)sum[0]; o8[1] = (uint8_t)sum[1]; o8[2] = (uint8_t)sum[2];
     }
   }

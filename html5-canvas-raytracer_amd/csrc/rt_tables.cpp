@@ -247,11 +247,12 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 
 // small launches have no tail worth ranking, and for very large ones (cfg5 on one GPU: 4.2 M workgroups, an 18 ms kernel) the
 // tail is noise; the COUNT variant and the A/B switch keep the grid's order as well
-bool table_is_ranked(bool ranked, uint64_t n_blocks) { return ranked && n_blocks >= 4096u && n_blocks <= (1u << 20); }
+// (ranked == 2: a compact band's launch - its blocks must come before the sky runs - is ranked whatever its size, up to the same limit)
+bool table_is_ranked(int ranked, uint64_t n_blocks) { return ranked && (n_blocks >= 4096u || ranked == 2) && n_blocks <= (1u << 20); }
 
 int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                       uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d,
-                      bool ranked, bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3],
+                      int ranked, bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3],
                       rt_table_params *P, std::vector<rt_ball> *balls, std::vector<rt_cost_rect> *rects) {
   const uint32_t ny = tiles->n_tiles * rb_per_tile;
   const uint64_t n64 = (uint64_t)tiles_x * ny;
@@ -331,7 +332,7 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
   // the costs a block of this launch can have: 1 .. cost_bins (what the ranking's per-row histograms are sized by); a launch whose
   // histograms would be unreasonably large (tens of thousands of row blocks AND many dear spheres) keeps the grid's order
   if (P->flags & RT_TABLE_RANK) {
-    uint64_t bound = 1u;
+    uint64_t bound = 2u;
     for (const rt_cost_rect &q : *rects) bound += q.weight;
     if (P->flags & RT_TABLE_BOUNCE) {                   // every mirror of a block may show every heavy sphere
       uint64_t heavy = 0u, mirrors = 0u;
@@ -348,7 +349,7 @@ int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std:
 // empty on a launch that is too large for the table)
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
-                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, int ranked,
                                          bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries, uint32_t sky_part) {
   if (n_entries) *n_entries = 0;
   rt_table_params P;

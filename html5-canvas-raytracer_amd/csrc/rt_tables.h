@@ -36,13 +36,13 @@ void scene_tile_weights(const rt_scene_header *hd, const rt_sphere *ob, std::vec
 // shadow a PRIMARY hit of the block, 0xffffffff = scan everything
 std::vector<uint32_t> build_launch_table(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                                          uint32_t w, uint32_t h, uint32_t ss,
-                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, bool ranked,
+                                         const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d, int ranked,
                                          bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3], uint32_t *n_entries, uint32_t sky_part = 0u);
 // the parameters, cone-test spheres and cost rectangles of a launch table (rt_block.h), shared by the host build and the GPU build;
 // returns non-zero when the launch is beyond the table
 int make_table_params(const rt_scene_header *hd, const rt_sphere *ob, const std::vector<rt_geom> &cull, const std::vector<uint32_t> &weight,
                       uint32_t w, uint32_t h, uint32_t ss, const rt_tiles *tiles, uint32_t tiles_x, uint32_t rb_per_tile, double proj_w, double proj_h, double proj_d,
-                      bool ranked, bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3],
+                      int ranked, bool mark_sky, uint32_t sky_sphere, bool shadow_masks, bool name_candidates, const double lights[][3],
                       rt_table_params *P, std::vector<rt_ball> *balls, std::vector<rt_cost_rect> *rects);
 constexpr uint32_t RT_ENTRY_WORDS = 4u;      // {tile_x | rows_valid << 11 | first frame row << 15, band row | run << 24 | sky << 31, shadow masks, primary candidates}
 

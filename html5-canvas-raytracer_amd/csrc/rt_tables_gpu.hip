@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(64) rt_table_scan(const rt_table_dev T) {
   }
   if (lane == 0u) {
     *T.ticket = 0u;                                       // for the next build
-    T.header[0] = total; T.header[1] = (total + 7u) / 8u; T.header[2] = 0u; T.header[3] = 0u;
+    // header: {entries, ceil(entries / 8), entries in front of the sky runs' class (a ranked table: its non-sky blocks; else all), 0}
+    T.header[0] = total; T.header[1] = (total + 7u) / 8u; T.header[2] = (P.flags & RT_TABLE_RANK) ? T.bin_start[bins - 1u] : total; T.header[3] = 0u;
     if (T.known) __hip_atomic_store(T.known, ((unsigned long long)T.known_tag << 32) | (total + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -33,6 +33,7 @@ RT_FLAG_STRICT_FP = 2
 RT_FLAG_RGB24 = 4        # device entry points: 3 bytes per pixel, the constant alpha stays home (include/rt_hip.h)
 RT_FLAG_NO_SKY = 8       # blocks that can only show the constant background are not stored (the frame's owner stores them: RT_FLAG_SKY_ONLY)
 RT_FLAG_SKY_ONLY = 16
+RT_FLAG_COMPACT = 32     # with RT_FLAG_RGB24 | RT_FLAG_NO_SKY: a compact band (the stored blocks back to back, for a collective)
 
 
 # --------------------------------------------------------------------------- scenes
@@ -176,6 +177,8 @@ ABI = {
     "rt_ipc_export": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rt_ipc_open": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_ipc_close": (C.c_int, [C.c_int, C.c_void_p]),
+    "rt_compact_count": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_compact_expand_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_deinterleave_rgb24_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_uint64, C.c_void_p]),
 }
@@ -263,6 +266,18 @@ class Renderer:
                                                C.byref(st) if st is not None else None)
         _check(self.lib, rc, "rt_render_scatter_device")
         return st
+
+    def compact_count(self, w, h, tiles, stream=None):
+        """(blocks, bytes per block) of a compact band (RT_FLAG_COMPACT) over `tiles` for the scene's current camera."""
+        t = tiles if isinstance(tiles, RtTiles) else RtTiles(*tiles)
+        n, bb = C.c_uint32(), C.c_uint32()
+        _check(self.lib, self.lib.rt_compact_count(self.handle, w, h, C.byref(t), C.c_void_p(stream or 0), C.byref(n), C.byref(bb)), "rt_compact_count")
+        return n.value, bb.value
+
+    def compact_expand(self, w, h, tiles, d_compact, d_frame, stream=None):
+        """Put the blocks of a compact band over `tiles` (rendered here or on a rank that holds the same scene and camera) back into the RGBA8 frame."""
+        t = tiles if isinstance(tiles, RtTiles) else RtTiles(*tiles)
+        _check(self.lib, self.lib.rt_compact_expand_device(self.handle, w, h, C.byref(t), C.c_void_p(d_compact), C.c_void_p(d_frame), C.c_void_p(stream or 0)), "rt_compact_expand_device")
 
     def close(self):
         if self.handle:

@@ -149,10 +149,16 @@ enum {
                              * reference's skybox with a plain colour, or the miss colour of main.js:231 - half of the headline frame) are
                              * NOT stored.  For a frame assembled from several GPUs' tiles in ONE buffer (rt_render_scatter_device into the
                              * owner's frame over xGMI): the senders leave the sky out ... */
-  RT_FLAG_SKY_ONLY = 16     /* ... and the frame's owner stores exactly those blocks, of whatever tiles the call names (the whole frame),
+  RT_FLAG_SKY_ONLY = 16,    /* ... and the frame's owner stores exactly those blocks, of whatever tiles the call names (the whole frame),
                              * from its own table: the two kinds of call together store every pixel once, and about half of the
                              * headline's pixels never cross a link.  Scenes without a constant background: RT_FLAG_NO_SKY leaves nothing
                              * out and RT_FLAG_SKY_ONLY stores nothing.  Not with RT_FLAG_COUNT. */
+  RT_FLAG_COMPACT = 32      /* rt_render_batch_device with RT_FLAG_RGB24 | RT_FLAG_NO_SKY: a COMPACT band for a collective - the blocks that
+                             * are stored at all (everything but the sky) back to back, block b of the launch (32 pixels x 8 rows, x 2
+                             * rows with supersample 2; RGB24, row by row: 768 / 192 bytes) at d_out + b * block_bytes, dearest block
+                             * first.  rt_compact_count says how many there are; the receiver, which holds the same scene with the same
+                             * camera, puts them back with rt_compact_expand_device and fills the sky itself (RT_FLAG_SKY_ONLY).  Not
+                             * for scenes the strict kernel renders (RT_ERR_UNSUPPORTED: send plain bands), not with RT_FLAG_COUNT. */
 };
 
 typedef struct rt_scene_dev rt_scene_dev; /* opaque: a scene resident in one GPU's HBM */
@@ -293,6 +299,16 @@ int rt_deinterleave_device(int device, const void *d_src, void *d_dst, uint32_t 
 int rt_deinterleave_rgb24_device(int device, const void *d_src, void *d_dst, uint32_t w, uint32_t h,
                                  uint32_t tile_rows, uint32_t n_ranks, uint64_t rank_stride_bytes,
                                  void *hip_stream);
+
+/* Compact bands (RT_FLAG_COMPACT).  rt_compact_count: for `tiles` of the w x h frame of a resident scene and its current camera, the
+ * number of blocks a compact launch stores and the bytes of one block; waits until the launch table behind the answer has been built
+ * (one small synchronous read).  The collective then moves n_blocks * block_bytes bytes instead of the band. */
+int rt_compact_count(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles, void *hip_stream, uint32_t *n_blocks, uint32_t *block_bytes);
+
+/* Put the blocks of a compact band back: `d_compact` holds what a launch with RT_FLAG_COMPACT over `tiles` stored - on this GPU or
+ * on another rank that holds the same scene with the same camera -; every pixel of every block goes to its place in the RGBA8 frame
+ * `d_frame` (w x h, alpha 255).  The sky blocks are not part of the band: the frame's owner stores them with RT_FLAG_SKY_ONLY. */
+int rt_compact_expand_device(rt_scene_dev *scene, uint32_t w, uint32_t h, const rt_tiles *tiles, const void *d_compact, void *d_frame, void *hip_stream);
 
 #ifdef __cplusplus
 }

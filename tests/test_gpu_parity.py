@@ -1526,3 +1526,84 @@ def test_adversarial_soak_seed_one_grazing_bounce_onto_a_fine_checker(lib):
         assert ou.max_lsb(got, want)[0] <= 1, flags
         if flags == FAST:
             assert st.exact_samples >= 1
+
+
+@pytest.mark.parametrize("scene,w,h,G,tile_rows", [("h8", 640, 360, 3, 16), ("h8", 3840, 2160, 2, 16), ("h8", 132, 77, 2, 8), ("cfg1", 256, 256, 4, 16), ("cfg2", 480, 270, 3, 8),
+                                                    ("default14", 320, 180, 2, 16), ("lcg64", 256, 128, 4, 8), ("lcg64_ss1", 3840, 2160, 8, 16), ("default14_stars", 160, 88, 2, 8)])
+def test_compact_bands_reassemble_the_frame(lib, scene, w, h, G, tile_rows):
+    """RT_FLAG_COMPACT (the exchange plan without the sky): every rank's band holds only the blocks it stores at all,
+    back to back in the order of its launch; rt_compact_count says how many; the receiver - the same scene, the same camera - puts
+    each band's blocks back (rt_compact_expand_device) and fills the sky itself (RT_FLAG_SKY_ONLY).  Together: the plain frame's
+    bytes.  For a scene with a constant background the bands are about half of the plain RGB24 bands."""
+    import shard
+    blob = rt_host.flatten_scene(rt_host.load_scene(scene))
+    want = gpu_frame(lib, blob, w, h)
+    plan = shard.TilePlan(w, h, tile_rows, G, 3)
+    r = rt_host.Renderer(blob, 0, lib)          # the sender ...
+    o = rt_host.Renderer(blob, 0, lib)          # ... and the frame's owner: its own resident copy of the scene, its own tables
+    n = w * h * 4
+    d = lib.rt_alloc_device(0, n)
+    band = lib.rt_alloc_device(0, plan.band_bytes + 1024)
+    flags = rt_host.RT_FLAG_RGB24 | rt_host.RT_FLAG_NO_SKY | rt_host.RT_FLAG_COMPACT
+    try:
+        assert lib.rt_memset_device(0, d, 0, n) == 0
+        total = 0
+        for g in range(G):
+            tiles = rt_host.RtTiles(*plan.rt_tiles(g))
+            blocks, block_bytes = r.compact_count(w, h, tiles)
+            assert block_bytes == 32 * 3 * (2 if rt_host.load_scene(scene).get("supersample", 1) == 2 else 8)
+            assert blocks * block_bytes <= plan.band_bytes + 32 * 3 * 8 * ((w + 31) // 32)      # (at most the band, padded to whole blocks)
+            assert o.compact_count(w, h, tiles) == (blocks, block_bytes)                         # both sides agree without talking
+            total += blocks * block_bytes
+            assert lib.rt_memset_device(0, band, 0xA5, plan.band_bytes + 1024) == 0
+            for _ in range(2):                                                                   # (second frame: its mark count is known)
+                r.render_batch(w, h, band, tiles, 1, 0, flags=flags, want_stats=True)
+            if blocks * block_bytes + 8 <= plan.band_bytes + 1024:
+                tail = C.create_string_buffer(8)
+                assert lib.rt_copy_to_host(0, tail, band + blocks * block_bytes, 8) == 0 and tail.raw == b"\xa5" * 8     # nothing stored behind the last block
+            o.compact_expand(w, h, tiles, band, d)
+        o.render_scatter(w, h, [d], rt_host.RtTiles(h, 0, 1, 1), flags=rt_host.RT_FLAG_SKY_ONLY, want_stats=True)
+        host = C.create_string_buffer(n)
+        assert lib.rt_copy_to_host(0, host, d, n) == 0
+        assert host.raw == want, scene
+        if scene in ("h8", "cfg1") and w >= 256:
+            assert total < 0.75 * w * h * 3, (total, w * h * 3)            # the sky stayed home
+    finally:
+        r.close()
+        o.close()
+        lib.rt_free_device(0, d)
+        lib.rt_free_device(0, band)
+
+
+def test_compact_bands_of_odd_frames_carry_the_centre_lines_and_strict_scenes_refuse(lib):
+    """An odd sample grid's centre row / column is traced again by the strict arithmetic (rt_retrace), which finds a sample's place in
+    a compact band from the table's own arrays; a scene the strict kernel renders throughout has no launch table: RT_ERR_UNSUPPORTED."""
+    import shard
+    w, h = 132, 77
+    blob = rt_host.flatten_scene(rt_host.load_scene("default14"))
+    want = gpu_frame(lib, blob, w, h)
+    r = rt_host.Renderer(blob, 0, lib)
+    d = lib.rt_alloc_device(0, w * h * 4)
+    band = lib.rt_alloc_device(0, w * h * 3 + 4096)
+    try:
+        assert lib.rt_memset_device(0, d, 0, w * h * 4) == 0
+        tiles = rt_host.RtTiles(h, 0, 1, 1)
+        st = r.render_batch(w, h, band, tiles, 1, 0, flags=rt_host.RT_FLAG_RGB24 | rt_host.RT_FLAG_NO_SKY | rt_host.RT_FLAG_COMPACT, want_stats=True)
+        assert st.exact_samples >= w                                       # the centre row (h is odd)
+        r.compact_expand(w, h, tiles, band, d)
+        r.render_scatter(w, h, [d], tiles, flags=rt_host.RT_FLAG_SKY_ONLY, want_stats=True)
+        host = C.create_string_buffer(w * h * 4)
+        assert lib.rt_copy_to_host(0, host, d, w * h * 4) == 0
+        assert host.raw == want
+    finally:
+        r.close()
+        lib.rt_free_device(0, d)
+        lib.rt_free_device(0, band)
+    s = rt_host.load_scene("h8")
+    s["lights"][0] = [0.0, 0.0, 0.0]                                        # a light ON the ground sphere: a strict-kernel scene
+    r = rt_host.Renderer(rt_host.flatten_scene(s), 0, lib)
+    try:
+        with pytest.raises(rt_host.RtError, match="strict kernel"):
+            r.compact_count(640, 360, rt_host.RtTiles(360, 0, 1, 1))
+    finally:
+        r.close()
