@@ -517,6 +517,23 @@ def main():
         a2a_channels = 3 if (multi and w % 4 == 0 and os.environ.get("RT_BENCH_RGBA_EXCHANGE") != "1") else 4
         plan = shard.TilePlan(w, h, TILE_ROWS, world, a2a_channels)
         batch_flags = flags | (rt_host.RT_FLAG_RGB24 if a2a_channels == 3 else 0)
+        # Single-frame mode, exchange plan: COMPACT bands (RT_FLAG_COMPACT) - only the blocks a rank stores at all, back to back, cross the
+        # links; rank 0 puts them back (rt_compact_expand_device, its own tables of every rank's tile set) and fills the sky itself.  The
+        # collective needs one message size: the largest rank's, known before the first step (rt_compact_count).  Scenes the strict kernel
+        # renders, 3x3 / 4x4 supersampling, RT_BENCH_NO_COMPACT=1: plain RGB24 bands as before.
+        compact = None
+        if multi and single and a2a_channels == 3 and not args.strict_fp:
+            mine = None
+            if os.environ.get("RT_BENCH_NO_COMPACT") != "1":
+                try:
+                    mine = renderer.compact_count(w, h, rt_host.RtTiles(*plan.rt_tiles(rank)))
+                except rt_host.RtError:
+                    mine = None
+            counts = [None] * world
+            dist.all_gather_object(counts, mine)
+            if all(c is not None for c in counts):
+                bb = counts[0][1]
+                compact = {"blocks": [c[0] for c in counts], "block_bytes": bb, "msg": ((max(c[0] for c in counts) * bb + 255) // 256) * 256}
         # a dedicated (non-null) HIP stream, made torch's current stream: the kernel launches, the
         # torch.cuda.Events that time them and c10d's stream dependencies all refer to this one stream
         # N>1: the render stream gets HIGH priority, so the exchange's copy kernels and the de-interleave (normal priority,
@@ -646,6 +663,11 @@ def main():
                 send = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
                 recv = [torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
                 host_recv = torch.empty((world, every, plan.band_rows, w, a2a_channels), dtype=torch.uint8) if rehearse else None
+            elif compact:
+                # [step of the group][the rank's blocks, padded to the largest rank's] on every rank; rank 0 gathers [source rank][step][blocks]
+                send = [torch.zeros((every, compact["msg"]), dtype=torch.uint8, device=dev) for _ in range(2)]
+                recv = [torch.empty((world, every, compact["msg"]), dtype=torch.uint8, device=dev) if i_own else None for _ in range(2)]
+                host_recv = torch.empty((world, every, compact["msg"]), dtype=torch.uint8) if (rehearse and i_own) else None
             else:
                 # [step of the group][band] on every rank; rank 0 gathers [source rank][step][band]
                 send = [torch.empty((every, plan.band_rows, w, a2a_channels), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -668,6 +690,8 @@ def main():
                     renderer.render_scatter(w, h, [my_buf + off], whole, stream=stream, flags=flags | rt_host.RT_FLAG_SKY_ONLY)
             elif not single:    # this rank's tiles of the `world` frames of this step, one launch: frame f -> send[slot][f, j]
                 renderer.render_batch(w, h, send[slot][0, j].data_ptr(), my_tiles, world, every * plan.band_bytes, stream=stream, flags=batch_flags)
+            elif compact:       # this rank's blocks of the step's one frame, the sky left out, back to back -> send[slot][j]
+                renderer.render_batch(w, h, send[slot][j].data_ptr(), my_tiles, 1, 0, stream=stream, flags=batch_flags | rt_host.RT_FLAG_NO_SKY | rt_host.RT_FLAG_COMPACT)
             else:               # this rank's tiles of the step's one frame -> send[slot][j]
                 renderer.render_batch(w, h, send[slot][j].data_ptr(), my_tiles, 1, 0, stream=stream, flags=batch_flags)
 
@@ -680,7 +704,13 @@ def main():
                 elif rehearse:
                     recv[slot].copy_(host_recv)
                 for j in range(count):                               # one whole frame per step of the group ends up on an owner
-                    shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
+                    if compact and single:
+                        # the sky of the whole frame from this rank's own table, then every rank's blocks to their places
+                        renderer.render_scatter(w, h, [frames[j].data_ptr()], whole, stream=side.cuda_stream, flags=flags | rt_host.RT_FLAG_SKY_ONLY)
+                        for g in range(world):
+                            renderer.compact_expand(w, h, rt_host.RtTiles(*plan.rt_tiles(g)), recv[slot][g, j].data_ptr(), frames[j].data_ptr(), stream=side.cuda_stream)
+                    else:
+                        shard.deinterleave(plan, recv[slot][:, j], frames[j], lib=lib, device_index=dev_index, stream=side.cuda_stream)
                 slot_free[slot].record(side)
             tstream.wait_event(slot_free[slot])                      # ordering only: that work is two groups old by the time it matters
 
@@ -876,6 +906,8 @@ def main():
             value = total_pixels / elapsed / 1e6
             flops_pp = 15.0 * tests_pp + 120.0 * rays_pp + 60.0 * shadow_pp        # SURVEY §8(d) algorithmic FP64 flop model
             algo_bytes = float(channels) * launch_pixels        # what one launch stores: RGBA8, or RGB24 bands at N>1
+            if compact and single and not mode["p2p"]:
+                algo_bytes = float(compact["blocks"][rank] * compact["block_bytes"])      # ... or only this rank's blocks (a compact band)
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             # HBM traffic and executed FP64 instructions per launch: PMC passes over a short child run of this same command
             traffic, traffic_src, fp64_measured = None, None, None
@@ -1005,6 +1037,13 @@ def main():
                                    "bytes_sent_per_rank_per_step": plan.band_bytes if single else (world - 1) * plan.band_bytes,
                                    "bytes_per_directed_link_per_step": plan.band_bytes, "bytes_per_pixel_on_the_link": channels,
                                    "steps_per_collective": every}
+                if compact and single:
+                    sent = sum(compact["blocks"]) * compact["block_bytes"]
+                    out["exchange"].update({"bands": "compact (RT_FLAG_COMPACT): the blocks a rank stores at all, back to back; rank 0 puts them back and fills the sky itself",
+                                            "bytes_sent_per_rank_per_step": compact["msg"], "bytes_per_directed_link_per_step": compact["msg"],
+                                            "bytes_of_blocks_per_rank": [b * compact["block_bytes"] for b in compact["blocks"]],
+                                            "bytes_sent_per_rank_per_step_with_the_sky": plan.band_bytes,
+                                            "sky_fraction_left_out": round(1.0 - sent / float(world * plan.band_bytes), 4)})
             if n1_mpix and single:
                 # the expectation this form is judged against (stated per N, so that the first run on real links has something to be held to)
                 k1 = w * h / n1_mpix / 1e3                                  # one GPU's ms per frame, this run

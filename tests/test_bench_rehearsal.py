@@ -84,6 +84,13 @@ def test_exchange_plan():
     assert out["exchange"]["collective"] == "gather to rank 0" and out["exchange"]["bytes_per_pixel_on_the_link"] == 3
     assert out["exchange"]["steps_per_collective"] == 4
     assert "plan_calibration_ms_per_step" not in out["config"]
+    # the gathered bands are COMPACT: the sky's blocks - about half of the headline frame - never cross a link in this plan either
+    ex = out["exchange"]
+    assert ex["bands"].startswith("compact") and 0.4 < ex["sky_fraction_left_out"] < 0.6
+    assert ex["bytes_sent_per_rank_per_step"] < 0.62 * ex["bytes_sent_per_rank_per_step_with_the_sky"]
+    assert abs(out["predicted"]["sky_fraction_left_out"] - ex["sky_fraction_left_out"]) < 1e-3 and out["predicted"]["bytes_per_pixel_on_the_link"] == 3
+    plain, _ = run_bench(2, RT_BENCH_P2P="0", RT_BENCH_NO_COMPACT="1", RT_BENCH_NO_BATCH="1")
+    assert "bands" not in plain["exchange"] and plain["exchange"]["bytes_sent_per_rank_per_step"] == ex["bytes_sent_per_rank_per_step_with_the_sky"]
     b = out["batch_mode"]
     assert b["scaling"] == "weak" and b["exchange"]["collective"] == "all_to_all_single" and b["exchange"]["steps_per_collective"] == 4
     assert out["n1_reference"]["mpixel_per_s"] > 0 and b["n1_reference"]["mpixel_per_s"] > 0
