@@ -7,7 +7,7 @@
 //
 //   GET /                               the page
 //   GET /frame?scene=h8&w=1280&h=720    raw RGBA8, w*h*4 bytes (ImageData.data layout);
-//                                       headers X-Width, X-Height, X-Kernel-Ms, X-Total-Ms, X-Build, X-Report ('build #741.r3 (12ms)')
+//                                       headers X-Width, X-Height, X-Kernel-Ms, X-Total-Ms, X-Build, X-Report ('build #741.r4 (12ms)')
 //   GET /frame?...&progressive=8        the same bytes as a CHUNKED response, one chunk per row band as it leaves the
 //                                       GPU (renderProgressive): the page paints top to bottom like the reference's
 //                                       scanline loop (main.js:183-201)

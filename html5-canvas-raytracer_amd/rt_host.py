@@ -292,7 +292,7 @@ class Renderer:
 
 
 def build_id(lib=None):
-    """`const build = '741'` (main.js:3) + the library's revision, e.g. '741.r3'."""
+    """`const build = '741'` (main.js:3) + the library's revision, e.g. '741.r4'."""
     return (lib or load_library()).rt_build_id().decode()
 
 

@@ -36,7 +36,7 @@ extern "C" {
 /* `const build = '741'` (main.js:3): the reference build whose per-pixel path this library reproduces, and this library's own
  * revision of it; rt_build_id() returns "<reference build>.<revision>". */
 #define RT_REFERENCE_BUILD "741"
-#define RT_LIBRARY_REVISION "r3"
+#define RT_LIBRARY_REVISION "r4"
 
 #define RT_MAX_OBJECTS  256u
 #define RT_MAX_LIGHTS   16u
@@ -169,7 +169,7 @@ void rt_shutdown(void);
 int rt_device_count(void);            /* GPUs in use after rt_init, or a negative rt_status */
 const char *rt_last_error(void);
 uint32_t rt_abi_version(void);
-const char *rt_build_id(void);        /* RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION, e.g. "741.r3" (main.js:3) */
+const char *rt_build_id(void);        /* RT_REFERENCE_BUILD "." RT_LIBRARY_REVISION, e.g. "741.r4" (main.js:3) */
 
 /* Validate a scene blob without touching a GPU (host logic; usable in CPU-only tests). */
 int rt_scene_validate(const void *scene_blob, size_t blob_bytes);
