@@ -822,7 +822,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
         const v3 l = inside ? mk(-n.x, -n.y, -n.z) : n;                 // hit.l, quirk q5
         const double a0 = m.albedo[0], a1 = m.albedo[1], a2 = m.albedo[2], a3 = m.albedo[3];
         const double a4 = REFRACT ? m.albedo[4] : 0.0;
-#if !RT_STRICT
+#if !RT_STRICT && !defined(RT_ABLATE_QAMP)     /* (RT_ABLATE_QAMP: timing experiment, profiles/ab_build.sh) */
         // Q of this hit (see above): for a bounced ray's hit, and for a primary hit that will spawn a ray (ht is at hand here)
         if (RT_LVL(level) != 0 || ((a3 > 0.0 || a4 > 0.0) && segs_left > 1)) {
           const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, (float)inv_r, __builtin_fabsf((float)dot(d, n)));
