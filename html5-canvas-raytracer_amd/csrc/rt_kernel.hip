@@ -877,7 +877,8 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           uint32_t iu = __builtin_amdgcn_alignbit((uint32_t)(su >> 32), (uint32_t)su, 20u) ^ 0x80000000u;       /* floor(x) for x in [0, 2^31) ... */ \
           uint32_t iv = __builtin_amdgcn_alignbit((uint32_t)(sv >> 32), (uint32_t)sv, 20u) ^ 0x80000000u;       \
           /* ... unless the fraction is within 2^-20 of an integer <=> the 20 fraction bits are 0xfffff, 0 or 1 (NaN, infinity: 0) */ \
-          if ((min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u)) {           \
+          /* ... or the hit's magnification bound Q is large (>= 2^14: the bfloat16 in the upper half of `level`): the cold block decides */ \
+          if ((min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u) | (((uint32_t)level >> 16) >= 0x4680u)) {           \
             RT_PIN();                                                                                             \
             iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \
@@ -900,7 +901,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             const bool zf = !(K->mark_flags & RT_MARK_ZERO);                                                       \
             const bool bu = (zf && (FU) == 0.0 && (XU) == 0.0) || (__builtin_fabs((XU) - __builtin_rint(XU)) >= tol);    \
             const bool bv = (zf && (FV) == 0.0 && (XV) == 0.0) || (__builtin_fabs((XV) - __builtin_rint(XV)) >= tol);    \
-            if (!(bu & bv)) {                                                                                     /* NaN: marked */ \
+            /* a hit whose coordinate error may exceed the prefilter's 2^-20 band (Q >= q_band: the scaled tolerance has reached half the \
+               band) is marked wherever its coordinate lies: the coarse test cannot vouch for it */                                  \
+            const bool qbig = (tol >= 0.0) && (q_here >= K->q_band);                                               \
+            if (!(bu & bv) | qbig) {                                                                              /* NaN: marked */ \
               uint32_t t3 = threadIdx.x;                                                                          \
               asm volatile("" : "+v"(t3));                                                                        \
               rt_mark_append<SS2>(rt_pixel_of<SS2>(L, t3));                                                        \

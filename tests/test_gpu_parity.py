@@ -1509,6 +1509,22 @@ def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
         assert got == gpu_frame(lib, blob, w, h, STRICT)
 
 
+def test_adversarial_soak_seed_beyond_the_prefilters_band(lib):
+    """The pixel the 300 000-scene adversarial soak at the round's first HEAD found (24 LSB): two bounces off small mirrors onto the floor's
+    checker at 1 000 000 squares per unit u; the coordinate's error (1.75e-6 squares) was LARGER than the hot path's 2^-20 prefilter
+    band, so the sample never reached the cold block whatever its tolerance.  A hit whose magnification bound says so (Q >= q_band) is
+    now marked wherever its coordinate lies."""
+    import soak_gpu_parity as soak
+    scene, w, h, tiles = soak.draw_adversarial(47438025)
+    rows = [8 * t + k for t in (tiles.tile_first, tiles.tile_first + tiles.tile_stride) for k in range(8)]
+    assert 3034 in rows
+    blob = rt_host.flatten_scene(scene)
+    want = ou.c_oracle_rows(blob, w, h, rows)
+    for flags in (FAST, STRICT):
+        got = gpu_tiles(lib, blob, w, h, (tiles.tile_rows, tiles.tile_first, tiles.tile_stride, tiles.n_tiles), flags)
+        assert ou.max_lsb(got, want)[0] <= 1, flags
+
+
 def test_adversarial_soak_seed_one_grazing_bounce_onto_a_fine_checker(lib):
     """The pixel the 102 000-scene adversarial soak found (profiles/r04_ab_log.md section 4): a primary ray grazes a mirror of radius
     ~0.1, its image lands 12.5 units away on the floor's checker at 100 000 squares per unit u, and the product kernel's own rounding,
