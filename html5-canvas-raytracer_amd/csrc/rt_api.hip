@@ -1231,7 +1231,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
   bind_kernel(L, strict_main);
   // the boundary test of the product kernel's samplers (rt_device.h)
   L.flag_tol = s->flag_tol;
-  L.q_band = (float)(4096.0 * (1.0 / 2097152.0) / s->flag_tol);       // RT_Q_FLAT x 2^-21 / flag_tol
   bool test_marks = false;               // test build: a switch that changes what is marked or re-traced - nothing is cached then
 #ifdef RT_TESTING
   if (const char *fs = getenv("RT_FLAG_SCALE")) { L.flag_tol *= atof(fs); test_marks = true; }        // a wider boundary band, to exercise the second launch

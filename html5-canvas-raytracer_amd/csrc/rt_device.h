@@ -105,7 +105,7 @@ struct rt_launch {
   uint32_t marks_cap;                // entries the list holds; beyond it only the count grows and rt_retrace traces every sample
   double flag_tol;                   // tolerance of the boundary test: RT_FLAG_T1 x the largest sampler frequency of the scene
   uint32_t mark_flags;               // RT_MARK_* (below)
-  float q_band;                      // the magnification bound Q (rt_kernel.hip) at which the scaled tolerance reaches half the hot path's 2^-20 band: beyond, a sampled hit is marked wherever its coordinate lies
+  uint32_t mark_pad;
   // rt_retrace only
   unsigned long long *marks_known;   // pinned host word that receives known_tag << 32 | count + 1, or NULL
   uint32_t known_tag;                // (the camera generation the frame is rendered with)

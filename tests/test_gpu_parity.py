@@ -1512,8 +1512,8 @@ def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
 def test_adversarial_soak_seed_beyond_the_prefilters_band(lib):
     """The pixel the 300 000-scene adversarial soak at the round's first HEAD found (24 LSB): two bounces off small mirrors onto the floor's
     checker at 1 000 000 squares per unit u; the coordinate's error (1.75e-6 squares) was LARGER than the hot path's 2^-20 prefilter
-    band, so the sample never reached the cold block whatever its tolerance.  A hit whose magnification bound says so (Q >= q_band) is
-    now marked wherever its coordinate lies."""
+    band, so the sample never reached the cold block whatever its tolerance.  Hits whose magnification bound is 2^14 or more now reach
+    the cold block's full-precision test unconditionally (below that the scaled tolerance cannot exceed the band)."""
     import soak_gpu_parity as soak
     scene, w, h, tiles = soak.draw_adversarial(47438025)
     rows = [8 * t + k for t in (tiles.tile_first, tiles.tile_first + tiles.tile_stride) for k in range(8)]
