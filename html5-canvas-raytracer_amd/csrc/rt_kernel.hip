@@ -536,9 +536,9 @@ __device__ __forceinline__ void rt_mark_append(const rt_pixel &P) {
 
 #if !RT_STRICT
 // Q of a hit from its parent's (see trace_pixel: "How far this kernel's own rounding has been magnified"): x = t / r, c = |d.n|
-__device__ __forceinline__ float rt_q_of(float qp, float x, float c) {
+__device__ __forceinline__ float rt_q_of(float qp, float x, float c, float rp_over_r) {
   const float ic = __builtin_amdgcn_rcpf(fmaxf(c, 1e-30f));                    // (s taken as 1: no square root on the way)
-  return fminf(ic * (qp * (6.f * x + 1.f) + x + 0.5f * x * x) + x, 1e30f);
+  return fminf(ic * (qp * (6.f * x + rp_over_r) + x + 0.5f * x * x) + x, 1e30f);
 }
 #endif
 
@@ -581,7 +581,9 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   // it, so the normal inherits (P + t D) / (r c); the distance itself, t = tca - thc, is rounded to ~eps t (1 + t / (2 r c)) - the
   // near root cancels when the ray grazes - and moves the hit along the ray, the normal by s / r of it; the mirrored (or refracted)
   // ray leaves with D' <= 3 D + 4 Q and P' = r Q.  With D dominated by the previous normal's error:
-  //     Q_hit = Q_parent (6 t / r + 1) / c  +  (t / r) (1 / c + s (1 + t / (2 r c))),        Q = 0 at the camera.
+  //     Q_hit = Q_parent (6 t + r_parent) / (r c)  +  (t / r) (1 / c + s (1 + t / (2 r c))),        Q = 0 at the camera
+  // (r_parent Q_parent is the origin's position error: from a small sphere onto a large one it all but vanishes; the parent's radius
+  // rides along as one exponent byte, rounded up).
   // A primary hit on the floor has Q ~ 1e-2, on the reference's small spheres 1e1 - 1e3; every bounce off a sphere of radius r at
   // distance t multiplies it by ~6 t / (r c), a grazing one by far more (profiles/r04_ab_log.md section 4: the adversarial soak's
   // flipped pixel had ONE bounce).  The samplers' boundary test scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below;
@@ -592,9 +594,12 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   // (it lives in the upper half of `level` as a bfloat16, rounded up: a 97th vector register would cost the kernel a wave per SIMD)
 #define RT_LVL(L_) ((L_) & 255)
 #define RT_Q_GET(L_) __builtin_bit_cast(float, (uint32_t)(L_) & 0xffff0000u)
-#define RT_Q_SET(L_, Q_) (L_) = (int)(((uint32_t)(L_) & 255u) | ((__builtin_bit_cast(uint32_t, (float)(Q_)) + 0xffffu) & 0xffff0000u))
+#define RT_Q_SET(L_, Q_) (L_) = (int)(((uint32_t)(L_) & 0xffffu) | ((__builtin_bit_cast(uint32_t, (float)(Q_)) + 0xffffu) & 0xffff0000u))
+  // bits 8..15: the exponent byte of a power of two >= the radius of the sphere this hit lies on (the next hit's r_parent)
+#define RT_R_GET(L_) __builtin_bit_cast(float, ((uint32_t)(L_) & 0xff00u) << 15)
+#define RT_R_SET(L_, INVR_) (L_) = (int)(((uint32_t)(L_) & 0xffff00ffu) | ((((__builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(INVR_)) >> 23) + 1u) & 255u) << 8))
 #define RT_Q_FLAT 4096.f
-#define RT_Q_OF(QP, T, INVR, C) rt_q_of((QP), (T) * (INVR), (C))
+#define RT_Q_OF(QP, T, INVR, C, RP) rt_q_of((QP), (T) * (INVR), (C), (RP) * (INVR))
 #else
 #define RT_LVL(L_) (L_)
 #endif
@@ -826,8 +831,10 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #if !RT_STRICT && !defined(RT_ABLATE_QAMP)     /* (RT_ABLATE_QAMP: timing experiment, profiles/ab_build.sh) */
         // Q of this hit (see above): for a bounced ray's hit, and for a primary hit that will spawn a ray (ht is at hand here)
         if (RT_LVL(level) != 0 || ((a3 > 0.0 || a4 > 0.0) && segs_left > 1)) {
-          const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, (float)inv_r, __builtin_fabsf((float)dot(d, n)));
+          const float ir_ = (float)inv_r;
+          const float q_ = RT_Q_OF(RT_Q_GET(level), (float)ht, ir_, __builtin_fabsf((float)dot(d, n)), RT_R_GET(level));
           RT_Q_SET(level, q_);
+          RT_R_SET(level, ir_);
         }
 #endif
 
@@ -889,7 +896,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             float q_here = RT_Q_GET(level);                                                                        \
             if (RT_LVL(level) == 0 && q_here == 0.f) {                  /* (a primary hit that spawns nothing: not filled in above) */ \
               const float ex = (float)(h.x - K->cam_origin[0]), ey = (float)(h.y - K->cam_origin[1]), ez = (float)(h.z - K->cam_origin[2]);   \
-              q_here = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, n)));       \
+              q_here = RT_Q_OF(0.f, __builtin_sqrtf(ex * ex + ey * ey + ez * ez), (float)m.inv_r, __builtin_fabsf((float)dot(d, n)), 0.f);       \
             }                                                                                                     \
             double tol = (K->mark_flags & RT_MARK_ALL) ? 2.0 : K->flag_tol * (double)fmaxf(1.f, q_here * (1.f / RT_Q_FLAT));   \
             /* ... and a sample whose colour cannot move the pixel by a byte is left alone: the pixel is F(x) = max(LO, min(HI, O + S x)) \
