@@ -509,9 +509,10 @@ extern "C" int rt_scene_upload(int device, const void *blob, size_t bytes, rt_sc
       }
     }
     // The hot path's prefilter passes coordinates within 2^-20 of an integer to the precise test against flag_tol = RT_FLAG_T1 x this
-    // frequency: above 2^20 per unit u the tolerance would approach the prefilter's band (equal at 4.7e6) and the margin over the
-    // product kernel's own error in a coordinate (~1e-16 x frequency) would shrink with it.  Such scenes take the strict kernel.
-    if (fmaxq > 1048576.0) s->needs_strict_scene = true;
+    // frequency, scaled by the hit's magnification bound (rt_kernel.hip): the band has to leave that scaling room.  Up to 2^17 per unit u
+    // it is 36 x the flat tolerance; the adversarial soak's second pixel (a checker at 1e6 per unit, two bounces: an error of 1.75e-6
+    // squares, beyond the band) is what set the limit.  Scenes with finer samplers take the strict kernel.
+    if (fmaxq > 131072.0) s->needs_strict_scene = true;
     s->flag_tol = RT_FLAG_T1 * fmaxq;
     // (boundary marks) every albedo and colour within [0, 1]: then a node's colour moves the pixel by at most its accumulated weight
     s->unit_weights = true;

@@ -587,8 +587,11 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   // A primary hit on the floor has Q ~ 1e-2, on the reference's small spheres 1e1 - 1e3; every bounce off a sphere of radius r at
   // distance t multiplies it by ~6 t / (r c), a grazing one by far more (profiles/r04_ab_log.md section 4: the adversarial soak's
   // flipped pixel had ONE bounce).  The samplers' boundary test scales its tolerance by max(1, Q / RT_Q_FLAT): RT_XY_INDEX below;
-  // RT_Q_FLAT is a third of the Q at which the flat tolerance (2e-13 in u, v = Q 1.1e-16 / 2 pi) is exactly the bound.  The hot path's
-  // prefilter (fraction within 2^-20 of an integer) vouches for hits with Q < 2^14 only; hits beyond go to the cold block unconditionally.  Updated per
+  // RT_Q_FLAT is a third of the Q at which the flat tolerance (2e-13 in u, v = Q 1.1e-16 / 2 pi) is exactly the bound.  The scaled tolerance is honoured
+  // up to the hot path's prefilter band (a fraction within 2^-20 of an integer): 36 x the flat tolerance at the largest admitted frequency
+  // (2^17 per unit; beyond, the scene is a strict scene), 950 x at the reference's 5000 - a bound that routes every high-Q sample to the
+  // cold block marks the reference's own scene's deep internal reflections by the dozen per frame (the recurrence is a worst case: inside a
+  // sphere errors do not compound the way it assumes), profiles/r04_ab_log.md section 4.  Updated per
   // BOUNCE, not per node: it is the Q of the current hit at every node below the primary, and is filled in for the primary when it
   // spawns a ray (at the node's top, where the hit's distance is at hand).
   // (it lives in the upper half of `level` as a bfloat16, rounded up: a 97th vector register would cost the kernel a wave per SIMD)
@@ -885,10 +888,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           uint32_t iu = __builtin_amdgcn_alignbit((uint32_t)(su >> 32), (uint32_t)su, 20u) ^ 0x80000000u;       /* floor(x) for x in [0, 2^31) ... */ \
           uint32_t iv = __builtin_amdgcn_alignbit((uint32_t)(sv >> 32), (uint32_t)sv, 20u) ^ 0x80000000u;       \
           /* ... unless the fraction is within 2^-20 of an integer <=> the 20 fraction bits are 0xfffff, 0 or 1 (NaN, infinity: 0) */ \
-          /* ... or the hit's magnification bound Q is 2^14 or more (the bfloat16 in the upper half of `level`): its scaled tolerance may \
-             exceed this band (below 2^14 it cannot: 4 x the flat tolerance <= 8.4e-7 at the largest admitted frequency), so the cold \
-             block's full-precision test sees EVERY such sample */ \
-          if ((min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u) | (((uint32_t)level >> 16) >= 0x4680u)) {           \
+          if ((min(((uint32_t)su + 1u) & 0xfffffu, ((uint32_t)sv + 1u) & 0xfffffu) <= 2u)) {           \
             RT_PIN();                                                                                             \
             iu = (uint32_t)(XU); iv = (uint32_t)(XV);                  /* truncation = floor (x >= 0); NaN -> 0 */  \
             const rt_launch __attribute__((address_space(4))) *K = rt_cold_args();                                \

@@ -1494,10 +1494,11 @@ def test_the_general_kernels_scratch_figure_is_what_the_code_object_says(lib):
     assert fn(1, 0, 0, 1, C.byref(b)) == 0 and 0 < b.value <= 4096    # the general kernel: the park stack
 
 
-@pytest.mark.parametrize("freq,strict_scene", [(1.0e6, False), (2.0e6, True)])
+@pytest.mark.parametrize("freq,strict_scene", [(1.0e5, False), (2.0e5, True)])
 def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
-    """the boundary tolerance 2e-13 x frequency must stay well inside the hot path's 2^-20 prefilter.  Up to 2^20 per unit
-    u the product path renders (tolerance <= 2.1e-7, a quarter of the band); beyond, the scene takes the strict kernel."""
+    """the boundary tolerance 2e-13 x frequency must stay well inside the hot path's 2^-20 prefilter.  Up to 2^17 per unit
+    u the product path renders (flat tolerance <= 2.6e-8, 1/36 of the band: room for the magnification scaling); beyond, the scene
+    takes the strict kernel."""
     s = rt_host.load_scene("h8")
     home = next(o for o in s["objects"] if o["mtl"]["sampler"]["kind"] == 2)
     home["mtl"]["sampler"]["freqU"], home["mtl"]["sampler"]["freqV"] = freq, freq / 2
@@ -1512,8 +1513,8 @@ def test_checker_frequencies_near_the_prefilters_band(lib, freq, strict_scene):
 def test_adversarial_soak_seed_beyond_the_prefilters_band(lib):
     """The pixel the 300 000-scene adversarial soak at the round's first HEAD found (24 LSB): two bounces off small mirrors onto the floor's
     checker at 1 000 000 squares per unit u; the coordinate's error (1.75e-6 squares) was LARGER than the hot path's 2^-20 prefilter
-    band, so the sample never reached the cold block whatever its tolerance.  Hits whose magnification bound is 2^14 or more now reach
-    the cold block's full-precision test unconditionally (below that the scaled tolerance cannot exceed the band)."""
+    band, so the sample never reached the cold block whatever its tolerance.  Samplers finer than 2^17 per unit now make the scene a
+    strict-kernel scene: up to there the band leaves the scaled tolerance a factor of 36 and more."""
     import soak_gpu_parity as soak
     scene, w, h, tiles = soak.draw_adversarial(47438025)
     rows = [8 * t + k for t in (tiles.tile_first, tiles.tile_first + tiles.tile_stride) for k in range(8)]
