@@ -1223,9 +1223,6 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
   };
   auto lds_for = [&](bool strict) {
-#ifdef RT_AB_GLOBAL_MTL
-    if (!strict && !count && !s->cull_in_lds) return lds_pad + (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u;      // EXPERIMENT: the many-sphere variant keeps only the fold state in LDS
-#endif
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
