@@ -684,3 +684,31 @@ def test_launch_table_lists_every_block_exactly_once(built, scene, w, h, tiles):
     costs = [cost(x, fr) for x, _, fr, _ in ranked]
     assert all(a >= b for a, b in zip(costs, costs[1:]))     # dearest first
     assert costs[0] > costs[-1]                              # ... and the frame does end on cheaper blocks (sky) than it starts with
+
+
+def test_dispatch_ranking_sees_what_a_blocks_mirrors_show(built):
+    """Round 4 (profiles/r04_ab_log.md section 2): in the reference's own scene the launch's last 70 us were waves of blocks that do not
+    SHOW the sphere with binary ray trees but MIRROR it - the small chrome sphere next to it (around tile_x 42, rows 1640-1664 of the
+    3840x2160 frame, then ranked ~7 000th of 16 000 entries), the flanks of the ornaments.  The ranking now adds, per reflecting
+    candidate of a block, half the weight of every two-child sphere its mirrored cone can meet (rt_block.h: rt_bounce_cost): those
+    blocks are dispatched right behind the two-child sphere's own (the first ~1 000 entries), far ahead of the ordinary mirrors."""
+    lib = rt_host.load_library()
+    blob = rt_host.flatten_scene(rt_host.load_scene("default14"))
+    buf = C.create_string_buffer(blob, len(blob))
+    w, h = 3840, 2160
+    t = rt_host.RtTiles(h, 0, 1, 1)
+    n, nb = C.c_uint32(), C.c_uint32()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), 7, None, C.byref(n), C.byref(nb)) == 0
+    n8 = (nb.value + 7) // 8
+    out = (C.c_uint32 * (32 * n8))()
+    assert lib.rt_scene_launch_table(buf, len(blob), w, h, C.byref(t), 7, out, C.byref(n), C.byref(nb)) == 0
+    ent = np.frombuffer(out, dtype=np.uint32).reshape(-1, 4)
+    b = np.arange(n.value)
+    e0 = ent[(b % 8) * n8 + b // 8, 0]
+    rank = {(int(x), int(y)): int(i) for i, x, y in zip(b, e0 & 2047, e0 >> 15)}
+    two_child = [rank[(tx, fr)] for tx in range(19, 27) for fr in range(1456, 1656, 8) if (tx, fr) in rank]      # the sphere's own middle (world x = +2.5: left of centre, the picture is mirrored)
+    chrome = [rank[(42, fr)] for fr in (1640, 1648, 1656, 1664)]                                               # the small chrome sphere beside it
+    assert max(two_child) < 1500, (min(two_child), max(two_child))                                            # (~940 blocks show that sphere; a few hundred that also show a mirror of it come first)
+    assert max(chrome) < 2500, chrome                                                                         # (round 3: 6 977 .. 7 052)
+    floor = [rank[(tx, 2000)] for tx in range(40, 80)]                                                        # plain floor: far behind both
+    assert min(floor) > max(chrome)
