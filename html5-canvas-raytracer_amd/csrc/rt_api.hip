@@ -1223,6 +1223,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
   };
   auto lds_for = [&](bool strict) {
+    // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS)
+    if (!strict && !count && !s->cull_in_lds && !s->refract) return lds_pad + 10u * RT_WG_THREADS * 8u;
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };

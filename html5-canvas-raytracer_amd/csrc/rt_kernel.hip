@@ -1187,7 +1187,19 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
               const v3 q = mk(__builtin_fma(l.x, t2, -sv.x), __builtin_fma(l.y, t2, -sv.y), __builtin_fma(l.z, t2, -sv.z));
               const double spd = -(d.x * q.x + d.y * q.y + d.z * q.z);
 #endif
+#if !RT_STRICT
+              // (materials in HBM - the reflection-only many-sphere variants -: the record's address is derived again here, from the hit
+              // code, so that no 64-bit pointer lives across the shadow scans)
+              double spec_e;
+              if constexpr (GRID && !REFRACT && !COUNT) {
+                uint32_t off_ = (uint32_t)hi * (uint32_t)sizeof(rt_mtl);
+                asm volatile("" : "+v"(off_));
+                spec_e = ((const rt_mtl *)((const char *)mtl + off_))->specular_exponent;
+              } else spec_e = m.specular_exponent;
+              if (spd > 0.0) specular += rt_pow(spd, spec_e);
+#else
               if (spd > 0.0) specular += rt_pow(spd, m.specular_exponent);
+#endif
             }
           }
           diffuse = min1(diffuse) * a1;
@@ -1416,6 +1428,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const bool cull_lds_on = (!RT_STRICT && !COUNT) ? !GRID : (L.cull_in_lds != 0u);      // (see trace_pixel)
   const uint32_t cull_words = cull_lds_on ? L.n_objects * 4u : 0u;     // per-sphere screen rectangles of the primary-ray cull (few spheres)
   const uint32_t image_words = mtl_words + tex_words + cull_words;
+  // The reflection-only many-sphere variants read materials and texture descriptors WHERE THEY ARE (HBM / L2 / L1: a 32-bit offset from
+  // a uniform base) instead of staging 10 KB of them per workgroup: LDS is then the fold state alone, 20 KB instead of 30 - a
+  // workgroup's LDS stays allocated until its slowest wave ends, and with 30 KB (five per CU) the dear two thirds of a launch kept
+  // only 66-78 % of the wave slots resident - and there is no staging and no barrier.  64 spheres: -3.8 % (3840x2160), -2.1 % (2x2),
+  // cfg5's full frame -2.6 % (profiles/r04_ab_log.md section 6).  (The general kernel keeps its image in LDS: it has no register to spare.)
+  constexpr bool IMAGE_IN_LDS = RT_STRICT || COUNT || !(GRID && !REFRACT);
+  const uint32_t lds_words = IMAGE_IN_LDS ? image_words : 0u;
   const double *__restrict__ image = (const double *)L.lds_image;
   // Few spheres (8: exactly one word per work-item): one 8-byte load each, a loop for the rest.  The many-sphere variant (64
   // spheres are 10.5 KB) moves 16 bytes per work-item and instruction, three 4 KB pieces unrolled with ALL their loads in flight
@@ -1427,17 +1446,18 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
   const uint32_t image_vec = image_words >> 1;                                     // 16-byte units (GRID: the image is whole units)
   [[maybe_unused]] rt_u4 piece[RT_STAGE_PIECES];
   [[maybe_unused]] double stage0 = 0.0;
-  if constexpr (GRID) {
+  if constexpr (!IMAGE_IN_LDS) {
+  } else if constexpr (GRID) {
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
     for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) if (i * RT_WG_THREADS < image_vec) piece[i] = image4[tid + i * RT_WG_THREADS];
   } else {
     stage0 = (tid < image_words) ? image[tid] : 0.0;
   }
-  const rt_mtl *mtl = (const rt_mtl *)lds_raw;
-  const rt_texture_desc *tex = (const rt_texture_desc *)(lds_raw + mtl_words);
+  const rt_mtl *mtl = IMAGE_IN_LDS ? (const rt_mtl *)lds_raw : (const rt_mtl *)L.lds_image;
+  const rt_texture_desc *tex = IMAGE_IN_LDS ? (const rt_texture_desc *)(lds_raw + mtl_words) : (const rt_texture_desc *)((const double *)L.lds_image + mtl_words);
   const rt_geom *cull_lds = (const rt_geom *)(lds_raw + mtl_words + tex_words);
-  double *acc = lds_raw + image_words + tid;   // fold state: 10 (general kernel: 13) x RT_WG_THREADS doubles, lane-major
+  double *acc = lds_raw + lds_words + tid;   // fold state: 10 (general kernel: 13) x RT_WG_THREADS doubles, lane-major
   // Many spheres: the primary-ray cull's rectangle of sphere `lane` (the wave's first 64 spheres) comes straight from HBM / L2,
   // in flight while the ray is generated, and is no part of the LDS image: 64 spheres + the fold state then fit 32 KB, five
   // workgroups per CU instead of four (64-sphere scenes -12 %; with 8 spheres the extra vector load costs 3 %, so few
@@ -1494,7 +1514,8 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #endif
 
   // finish the staging (first use of LDS: the cull table or the closest hit's material inside trace_pixel)
-  if constexpr (GRID) {
+  if constexpr (!IMAGE_IN_LDS) {
+  } else if constexpr (GRID) {
     rt_u4 *lds4 = (rt_u4 *)lds_raw;
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
@@ -1507,7 +1528,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     if (tid < image_words) lds_raw[tid] = stage0;
     for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
   }
-  __syncthreads();
+  if constexpr (IMAGE_IN_LDS) __syncthreads();
 
   // this wave's pixel block in the units of d0/d1 (every lane holds the same four numbers)
   const double bw = SS2 ? 15.0 : 7.0, bh = SS2 ? 3.0 : 7.0;
@@ -1556,7 +1577,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
     // of an xGMI link has no L2 of ours in front of it to merge them.  So the workgroup transposes its 32x8 tile through
     // LDS - every lane parks its pixel in its own fold-state slot 0, dead by now - and each wave then stores two whole
     // 128-byte rows of the tile.
-    uint32_t *tile = (uint32_t *)(lds_raw + image_words);
+    uint32_t *tile = (uint32_t *)(lds_raw + lds_words);
     tile[2u * tid2] = rgbw;
     __syncthreads();
     const uint32_t xr = tid2 & 31u, rr = tid2 >> 5;     // this work-item's pixel of the tile in row-major order

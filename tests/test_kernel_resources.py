@@ -42,7 +42,11 @@ def test_product_kernels_fit_five_waves(built, tmp_path):
     for (refract, count, ss2, grid), r in k.items():
         # no spill anywhere, vector or scalar (round 2's many-sphere variants had 1 + 16..18: cold launch-record fields are now read
         # from the kernarg segment where they are used, the trig coefficients come in 32-byte groups)
-        assert r["vgpr_spill_count"] == 0 and (count or r["sgpr_spill_count"] == 0), (refract, count, ss2, grid, r)
+        # ... but one: cfg5's variant (reflection-only, 2x2 supersampling, many spheres) since it reads its materials from HBM instead of
+        # staging them in LDS (round 4: -2.6 % on cfg5's frame, profiles/r04_ab_log.md section 6) spills ONE vector register (one store and
+        # one load per node) and four scalar ones: measured faster with them than without the change
+        cfg5_variant = (refract, count, ss2, grid) == (0, 0, 1, 1)
+        assert r["vgpr_spill_count"] <= (1 if cfg5_variant else 0) and (count or r["sgpr_spill_count"] <= (4 if cfg5_variant else 0)), (refract, count, ss2, grid, r)
         assert r["max_flat_workgroup_size"] == 256
         if count:
             continue                                  # the counting kernels are a test aid, not a product path
@@ -50,7 +54,7 @@ def test_product_kernels_fit_five_waves(built, tmp_path):
         # chain scenes keep their fold state in LDS and need no scratch; the general kernel's only private memory is
         # the explicit two-child park stack
         if not refract:
-            assert r["private_segment_fixed_size"] == 0, (refract, count, ss2, grid, r)
+            assert r["private_segment_fixed_size"] <= (16 if cfg5_variant else 0), (refract, count, ss2, grid, r)
 
 
 def test_strict_kernels_do_not_spill(built, tmp_path):
