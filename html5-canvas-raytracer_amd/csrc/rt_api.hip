@@ -1343,7 +1343,22 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     L.order = oe.Tb[s->cam_gen & 1u].entries;
     // one workgroup per table entry (runs of sky blocks share one).  How many there are is known on the device; until the build's
     // count has reached the host, one workgroup per BLOCK is launched: those behind the last entry read a zero slot and leave
-    const uint32_t n_known = known_value(oe.known, s->cam_gen);
+    uint32_t n_known = known_value(oe.known, s->cam_gen);
+    // A table that rt_scene_set_camera is rebuilding on the side stream - beside the previous frame's trace - publishes its count
+    // while that trace is still running.  A caller that issues frames back to back arrives here earlier than that: it is given a
+    // short, BOUNDED wait for the word (it is ahead of the GPU anyway, and stays one frame ahead: the trace in flight has tens of
+    // microseconds left when the word arrives); one workgroup per block costs a 4K frame 80 us instead of 68.  A caller that comes
+    // later (a frame per display refresh) finds the word there; a word that does not come in time: one workgroup per block.
+    if (!n_known && oe.built_on == s->side && oe.cam_gen == s->cam_gen) {
+      // (the bound grows with the table: a 4K frame's build takes ~50 us beside a trace, an 8K frame's four times that)
+      static const long wait_env = RT_TEST_ENV("RT_COUNT_WAIT_US") ? atol(RT_TEST_ENV("RT_COUNT_WAIT_US")) : -1;       // A/B switch (test build)
+      const long wait_us = wait_env >= 0 ? wait_env : 100 + (long)(oe.n_blocks / 256u);
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!n_known && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < wait_us) {
+        __builtin_ia32_pause();
+        n_known = known_value(oe.known, s->cam_gen);
+      }
+    }
     L.order_n8 = (oe.n_blocks + 7u) / 8u;
     L.grid_x = n_known ? n_known - 1u : oe.n_blocks;
     L.grid_y = 1u;

@@ -210,7 +210,9 @@ void rt_scene_free(rt_scene_dev *scene);
  * new block and rebuilds those tables ON THE GPU on a stream of the library's own, beside the previous camera's frames that are
  * still rendering, and the next render of the scene waits for them by event (no host wait).  A plain loop
  * `rt_scene_set_camera; rt_render_tiles_device; ...` on ONE stream therefore overlaps a frame's table build with its predecessor's
- * trace.  `hip_stream` is accepted for source compatibility and not used.  Renders of one scene belong on one stream (several
+ * trace.  (The one host wait in that loop is bounded: the render that follows a move so closely that the rebuilt table's entry
+ * count has not reached the host yet waits for it for at most 0.1 ms + 1 us per 256 blocks - the caller is ahead of the GPU
+ * then - and launches one workgroup per block if it does not come.)  `hip_stream` is accepted for source compatibility and not used.  Renders of one scene belong on one stream (several
  * work: a move then drains the device first).  Camera moves and renders of ONE scene handle must not be issued concurrently from
  * different threads (renders among themselves may).  A camera that crosses the scene's enclosing sphere (a skybox) is
  * RT_ERR_UNSUPPORTED: upload the scene again. */
