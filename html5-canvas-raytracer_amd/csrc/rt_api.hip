@@ -28,8 +28,8 @@
 extern "C" int rt_launch_trace_fast(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_trace_strict(const rt_launch *, int, int, int, unsigned, hipStream_t);
 extern "C" int rt_launch_retrace(const rt_launch *, int, int, unsigned, hipStream_t);
-extern "C" int rt_scratch_trace_fast(int, int, int, int, size_t *);
-extern "C" int rt_scratch_trace_strict(int, int, int, int, size_t *);
+extern "C" int rt_scratch_trace_fast(int, int, int, int, int, size_t *);
+extern "C" int rt_scratch_trace_strict(int, int, int, int, int, size_t *);
 extern "C" int rt_scratch_retrace(int, int, size_t *);
 
 using namespace rt_tables;   // the host-built tables (pure host logic, rt_tables.cpp)
@@ -152,15 +152,15 @@ int scratch_guard(device_state &D, hipStream_t stream, size_t per_lane, uint64_t
 }
 
 // per-lane scratch of a kernel instantiation, from its code object (asked once per instantiation)
-int kernel_scratch(bool strict, bool retrace, int refract, int count, int ss2, int grid_variant, size_t *out) {
+int kernel_scratch(bool strict, bool retrace, int refract, int count, int ss2, int grid_variant, size_t *out, bool one_wave = false) {
   static std::mutex mu;
-  static size_t cache[3][2][2][2][2];
-  static bool have[3][2][2][2][2];
-  const int k = retrace ? 2 : (strict ? 1 : 0), c = retrace ? 0 : (count ? 1 : 0), g = (retrace || strict) ? 0 : (grid_variant ? 1 : 0);
+  static size_t cache[3][2][2][2][3];
+  static bool have[3][2][2][2][3];
+  const int k = retrace ? 2 : (strict ? 1 : 0), c = retrace ? 0 : (count ? 1 : 0), g = (retrace || strict) ? 0 : (grid_variant ? (one_wave ? 2 : 1) : 0);
   std::lock_guard<std::mutex> lk(mu);
   if (!have[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g]) {
     size_t b = 0;
-    const int e = retrace ? rt_scratch_retrace(refract, ss2, &b) : (strict ? rt_scratch_trace_strict(refract, count, ss2, 0, &b) : rt_scratch_trace_fast(refract, count, ss2, grid_variant, &b));
+    const int e = retrace ? rt_scratch_retrace(refract, ss2, &b) : (strict ? rt_scratch_trace_strict(refract, count, ss2, 0, 0, &b) : rt_scratch_trace_fast(refract, count, ss2, grid_variant, one_wave ? 1 : 0, &b));
     if (e != 0) return fail(RT_ERR_DEVICE, "hipFuncGetAttributes: %s", hipGetErrorString((hipError_t)e));
     cache[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g] = b; have[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g] = true;
   }
@@ -1223,8 +1223,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     }
   };
   auto lds_for = [&](bool strict) {
-    // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS)
-    if (!strict && !count && !s->cull_in_lds && !s->refract) return lds_pad + 10u * RT_WG_THREADS * 8u;
+    // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS - and run one-wave
+    // workgroups, rt_device.h, unless they store through the peer-store path)
+    if (!strict && !count && !s->cull_in_lds && !s->refract)
+      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, s->cull_in_lds, d_frames != nullptr) ? 64u : RT_WG_THREADS) * 8u;
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
@@ -1398,13 +1400,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     } else {
     {
       size_t per_lane = 0;
-      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane))) return rc;
+      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.cull_in_lds != 0u, L.scatter != 0u)))) return rc;
       if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
     }
 #ifdef RT_WAVE_LOG
     // measurement build: RT_WAVE_LOG_FILE=<path> - every wave's entry / exit time and place of THIS launch, written after it has finished
     unsigned long long *d_wave_log = nullptr;
-    const size_t wave_log_words = (size_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u) * 4u;
+    const size_t wave_log_words = (size_t)((L.grid_x + 7u) / 8u * 8u) * n_frames * (RT_WG_THREADS / 64u) * 4u;
     if (getenv("RT_WAVE_LOG_FILE")) {
       if (hipMalloc((void **)&d_wave_log, wave_log_words * 8u) == hipSuccess) (void)hipMemsetAsync(d_wave_log, 0, wave_log_words * 8u, stream);
       L.wave_log = d_wave_log;

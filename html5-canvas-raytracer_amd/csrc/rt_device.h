@@ -13,6 +13,12 @@
 #define RT_WG_THREADS 256
 #endif
 #define RT_TILE_W (RT_WG_THREADS / 8)   /* waves side by side, 8 pixels each */
+/* Which product launches run ONE-WAVE workgroups (four per launch-table entry; rt_kernel.hip: W1): the reflection-only many-sphere
+ * variants - nothing staged, only the fold state in LDS - unless the launch stores through the peer-store path, which puts whole
+ * 128-byte lines together across a workgroup's four waves.  Host (LDS size, scratch figure) and launcher ask the same question. */
+static inline bool rt_one_wave_workgroups(bool strict, bool count, bool refract, bool cull_in_lds, bool scatter) {
+  return !strict && !count && !refract && !cull_in_lds && !scatter;
+}
 #define RT_TILE_H 8
 
 // Shadow grid (product kernel, scenes with more than RT_SGRID_MIN_LOOP spheres in the loops): cells per axis of a

@@ -413,8 +413,24 @@ typedef const rt_sphere __attribute__((address_space(4))) *sphere_kptr;
 // again after the trace, behind an opaque copy of the id — so that px / lrow / valid are not kept live in VGPRs across
 // the whole trace (they would be the 97th register: the kernel fits the 96 of 5 waves per SIMD without them).
 struct rt_pixel { uint32_t px, trow, frow, lrow, sub, rows_valid, run, cand; bool valid, sky; };
+// W1 - ONE-WAVE workgroups (the reflection-only many-sphere variants, rt_trace): the entry's 32 x 8 block is rendered by FOUR
+// workgroups of one wave each, workgroup b = xcd + 8 * (wave + 4 * e') for entry e = 8 e' + xcd: the four waves of a block are
+// consecutive workgroups of ONE XCD, and an XCD still reads one contiguous eighth of the table.
+template <bool W1>
+__device__ __forceinline__ uint32_t rt_entry_slot(const rt_launch &L) {
+  // entry of workgroup b at (b % 8) * ceil(n / 8) + b / 8: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+  // correctness), so each XCD's L2 reads one contiguous eighth of the table instead of every line of it
+  return (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> (W1 ? 5 : 3));
+}
+// (the entry's index in the table's order: a compact band's block number)
+template <bool W1>
+__device__ __forceinline__ uint32_t rt_entry_index() { return W1 ? (((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u)) : blockIdx.x; }
+// (which of the block's four 8-pixel columns this wave renders)
+template <bool W1>
+__device__ __forceinline__ uint32_t rt_wave_of(uint32_t tid) { return W1 ? ((blockIdx.x >> 3) & 3u) : tid >> 6; }
+
 #if RT_STRICT
-template <bool SS2>
+template <bool SS2, bool W1 = false>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   // grid = (tiles across the frame, tiles x row blocks per tile, frames of the batch).  y splits into
@@ -443,15 +459,13 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
 // (built on the GPU per camera, frame size and tile set: rt_tables_gpu.hip, rt_block.h).  One scalar load replaces the tile /
 // row-block arithmetic of the plain grid - no division, no tile parameters in registers - and decides the ORDER in which the
 // hardware hands the tiles out: dearest first, so that a launch ends on cheap sky tiles instead of on the floor.  trow is the row
-// inside the workgroup's block here.
-template <bool SS2>
+// inside the workgroup's block here.  (W1: rt_entry_slot above.)
+template <bool SS2, bool W1 = false>
 __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid) {
-  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const uint32_t wave = rt_wave_of<W1>(tid), lane = tid & 63u;
   typedef uint32_t __attribute__((ext_vector_type(4))) rt_entry;                                     // 16 bytes (rt_tables.h: RT_ENTRY_WORDS)
   typedef const rt_entry __attribute__((address_space(4))) *order_kptr;
-  // entry of workgroup b at (b % 8) * ceil(n / 8) + b / 8: workgroups are dealt round-robin over the 8 XCDs (speed only, never
-  // correctness), so each XCD's L2 reads one contiguous eighth of the table instead of every line of it
-  const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
+  const uint32_t slot = rt_entry_slot<W1>(L);
   const rt_entry e4 = *(order_kptr)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 4));   // s_load_dwordx4
   const uint32_t e0 = e4.x, e1 = e4.y;
   const uint32_t tile_x = e0 & 2047u, rows_valid = (e0 >> 11) & 15u, frow0 = e0 >> 15;
@@ -474,8 +488,9 @@ __device__ __forceinline__ rt_pixel rt_pixel_of(const rt_launch &L, uint32_t tid
 // Word 2 of this workgroup's launch-table entry: per light, the 16-bit set of loop-order spheres that can shadow a primary hit of
 // its block (rt_block.h), or ~0u.  Read again where it is used - the primary node's lighting - instead of being kept in a
 // scalar register across the cull and the search (the kernel has none to spare).
+template <bool W1>
 __device__ __forceinline__ uint32_t rt_entry_shadow_masks(const rt_launch &L) {
-  const uint32_t slot = (blockIdx.x & 7u) * L.order_n8 + (blockIdx.x >> 3);
+  const uint32_t slot = rt_entry_slot<W1>(L);
   return *(const uint32_t __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)L.order + ((size_t)slot << 4) + 8u);
 }
 #endif
@@ -542,7 +557,7 @@ __device__ __forceinline__ float rt_q_of(float qp, float x, float c, float rp_ov
 }
 #endif
 
-template <bool REFRACT, bool COUNT, bool GRID, bool SS2, bool ITEM = false>
+template <bool REFRACT, bool COUNT, bool GRID, bool SS2, bool ITEM = false, bool W1 = false>
 __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mtl, const rt_texture_desc *tex,
                                             [[maybe_unused]] double *acc, [[maybe_unused]] const rt_geom *cull_lds, [[maybe_unused]] const rt_geom cull0, [[maybe_unused]] uint32_t lane,
                                             [[maybe_unused]] double blk_x0, [[maybe_unused]] double blk_x1, [[maybe_unused]] double blk_y0,
@@ -914,7 +929,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
             if (!(bu & bv)) {                                                                                     /* NaN: marked */ \
               uint32_t t3 = threadIdx.x;                                                                          \
               asm volatile("" : "+v"(t3));                                                                        \
-              rt_mark_append<SS2>(rt_pixel_of<SS2>(L, t3));                                                        \
+              rt_mark_append<SS2>(rt_pixel_of<SS2, W1>(L, t3));                                                        \
             }                                                                                                     \
           }
         if (kind == RT_SAMPLER_TEXTURE) {
@@ -949,7 +964,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           if constexpr (!ITEM) {
             uint32_t t3 = threadIdx.x;
             asm volatile("" : "+v"(t3));
-            const rt_pixel P = rt_pixel_of<SS2>(L, t3);
+            const rt_pixel P = rt_pixel_of<SS2, W1>(L, t3);
             sx = SS2 ? 2u * P.px + (P.sub & 1u) : P.px; sy = SS2 ? 2u * P.frow + (P.sub >> 1) : P.frow;
           }
           const unsigned long long pix = (unsigned long long)sy * (SS2 ? 2u * L.w : L.w) + sx;
@@ -981,7 +996,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 #endif
 #if !RT_STRICT
           [[maybe_unused]] uint32_t smask = ~0u;
-          if constexpr (!COUNT) { if (primary_node) smask = rt_entry_shadow_masks(L); }
+          if constexpr (!COUNT) { if (primary_node) smask = rt_entry_shadow_masks<W1>(L); }
 #endif
           for (uint32_t k = 0; k < NL; k++) {
             double llen;
@@ -1266,7 +1281,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
           // A node with BOTH children (a bubble) is parked with the map accumulated so far, its reflection subtree is
           // traced under a fresh (identity) map, and when that subtree's colour is known the node continues as a
           // one-child node through its refraction ray (main.js:268-278: reflection is evaluated before refraction).
-          const uint32_t T = RT_WG_THREADS;
+          const uint32_t T = W1 ? 64u : RT_WG_THREADS;
           double A[3], D[3];
 #pragma unroll
           for (int c = 0; c < 3; c++) { A[c] = col[c] * a0; D[c] = col[c] * diffuse + col[c] * specular; }
@@ -1327,7 +1342,7 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
 
       if constexpr (FOLD_FORWARD) {
         // a chain of one-child nodes ended with colour `ret`: apply the accumulated map once
-        const uint32_t T = RT_WG_THREADS;
+        const uint32_t T = W1 ? 64u : RT_WG_THREADS;
         if (map_valid) {
           const double S = acc[0];
 #pragma unroll
@@ -1404,19 +1419,28 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
 }
 
-template <bool REFRACT, bool COUNT, bool SS2, bool GRID>
+// W1: one-wave workgroups (rt_pixel_of), for the reflection-only many-sphere variants - the ones that stage nothing and keep only
+// the fold state in LDS.  A workgroup's waves are placed together: a 4-wave workgroup starts when its CU has room for all four, and
+// where the waves of a launch differ in length - the dear two thirds of a 64-sphere frame: 3 400 - 4 100 of the chip's 5 120 wave
+// slots resident (profiles/wave_timeline.py) - slots wait for their neighbours.  One wave per workgroup fills every slot as it frees:
+// 64 spheres 3840x2160 2x2 -7.6 %, cfg5's frame -6.1 %; kernels that stage an image per workgroup lose (headline +0.5 %, 8K +1.3 %:
+// four times the staging), so they keep four waves (profiles/r04_ab_log.md section 8).  The peer-store path keeps four waves too
+// (it puts whole 128-byte lines together across the workgroup's waves).
+template <bool REFRACT, bool COUNT, bool SS2, bool GRID, bool W1 = false>
 // Register budget: the reflection-only kernel fits 96 VGPRs = 5 waves per SIMD on its own (measured: 4 waves cost 11 %,
 // more than 5 gain nothing); its shadow-grid variant is held there; the general kernel is left free (forcing it to 5
 // waves spills into its loops: -9 %).
-__global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_PER_EU : (RT_WAVES_PER_EU > 5 ? RT_WAVES_PER_EU : 5))) rt_trace(const rt_launch L) {
+__global__ void __launch_bounds__(W1 ? 64 : RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_PER_EU : (RT_WAVES_PER_EU > 5 ? RT_WAVES_PER_EU : 5))) rt_trace(const rt_launch L) {
+  static_assert(!W1 || (GRID && !REFRACT && !COUNT && !RT_STRICT), "one-wave workgroups: the variants that stage nothing");
+  [[maybe_unused]] constexpr uint32_t WG_WAVES = W1 ? 1u : RT_WG_THREADS / 64u;
   extern __shared__ double lds_raw[];
 #if defined(RT_WAVE_LOG) && !RT_STRICT
   // measurement build: when this wave started, and where (nothing is kept in registers: the exit stamp recomputes its slot)
   if (unsigned long long *const wl = rt_cold_args()->wave_log; wl != nullptr && (threadIdx.x & 63u) == 0u) {
-    unsigned long long *q = wl + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (RT_WG_THREADS / 64u) + (threadIdx.x >> 6)) * 4u;
+    unsigned long long *q = wl + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * WG_WAVES + (threadIdx.x >> 6)) * 4u;
     q[0] = __builtin_amdgcn_s_memrealtime();
     q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4u) | (0u << 6) | (31u << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20u) | (0u << 6) | (31u << 11)) << 32);
-    q[3] = blockIdx.x;
+    q[3] = rt_entry_index<W1>();
   }
 #endif
   // ---- stage the per-workgroup tables into LDS: ONE contiguous image in HBM (materials | texture descriptors |
@@ -1467,7 +1491,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 
   // ---- which pixel / sample this work-item owns ----
   const uint32_t lane = tid & 63u;
-  const rt_pixel P0 = rt_pixel_of<SS2>(L, tid);
+  const rt_pixel P0 = rt_pixel_of<SS2, W1>(L, tid);
 #if !RT_STRICT
   // workgroup-uniform: a block wholly past its tile's or the frame's last row - or no entry at all: while the host does not know how
   // many entries a table built on the GPU a moment ago has, it launches one workgroup per BLOCK, and the slots behind the last
@@ -1540,13 +1564,13 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #else
   const bool is_probe = false;
 #endif
-  trace_pixel<REFRACT, COUNT, GRID, SS2>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe, P0.cand);
+  trace_pixel<REFRACT, COUNT, GRID, SS2, false, W1>(L, mtl, tex, acc, cull_lds, cull0, lane, blk_x0, blk_x1, blk_y0, blk_y1, o, ray, rgb, cnt, is_probe, P0.cand);
   }
 
   // ---- A10 RGBA8 store ----
   uint32_t tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));                       // opaque: recompute the pixel instead of keeping it live (see rt_pixel_of)
-  const rt_pixel P1 = rt_pixel_of<SS2>(L, tid2);
+  const rt_pixel P1 = rt_pixel_of<SS2, W1>(L, tid2);
   const uint32_t frame_i = blockIdx.z;
   const bool valid = P1.valid;
   const uint32_t r8 = to_byte(rgb[0]), g8 = to_byte(rgb[1]), b8 = to_byte(rgb[2]);
@@ -1572,7 +1596,7 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #else
   const uint32_t n_run = P1.sky ? P1.run : 1u;
 #endif
-  if (!L.rgb24 && L.scatter && !SS2) {                 // workgroup-uniform
+  if (!W1 && !L.rgb24 && L.scatter && !SS2) {          // workgroup-uniform (the host launches the four-wave variant for scatter stores)
     // Peer stores want whole lines: a wave's 8x8 block is eight 32-byte pieces, one per row, and memory on the far side
     // of an xGMI link has no L2 of ours in front of it to merge them.  So the workgroup transposes its 32x8 tile through
     // LDS - every lane parks its pixel in its own fold-state slot 0, dead by now - and each wave then stores two whole
@@ -1625,14 +1649,14 @@ __global__ void __launch_bounds__(RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_
 #endif
       if (!(row_ok && j < in_row && P1.sub == 0u)) continue;
       // RT_FLAG_COMPACT: the block whole, at its place in the LAUNCH (a compact band: rows of 32 pixels = 24 words, 8 - or 2 - of them)
-      if (L.compact) out[(size_t)blockIdx.x * (RT_TILE_W * 3u / 4u * (SS2 ? 2u : RT_TILE_H)) + P1.trow * (RT_TILE_W * 3u / 4u) + (((tid2 >> 6) * 8u) >> 2) * 3u + j] = word;
+      if (L.compact) out[(size_t)rt_entry_index<W1>() * (RT_TILE_W * 3u / 4u * (SS2 ? 2u : RT_TILE_H)) + P1.trow * (RT_TILE_W * 3u / 4u) + ((rt_wave_of<W1>(tid2) * 8u) >> 2) * 3u + j] = word;
       else out[((P1.lrow * L.w + x0) >> 2) * 3u + j] = word;
     }
   }
 
 #if defined(RT_WAVE_LOG) && !RT_STRICT
   if (unsigned long long *const wl = rt_cold_args()->wave_log; wl != nullptr && (tid2 & 63u) == 0u)
-    wl[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (RT_WG_THREADS / 64u) + (tid2 >> 6)) * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+    wl[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * WG_WAVES + (tid2 >> 6)) * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
 #endif
   if (COUNT) {
 #pragma unroll
@@ -1762,12 +1786,13 @@ extern "C" int rt_launch_retrace(const rt_launch *L, int refract, int ss2, unsig
 
 // Scratch (private segment) bytes per lane of the kernel instantiation the launcher below would pick, from the code object: what the
 // runtime reserves for every wave slot of the device before the first launch (rt_api.hip: scratch_guard).  Returns a hipError_t as int.
-extern "C" int RT_SCRATCH_NAME(int refract, int count, int ss2, int grid_variant, size_t *bytes_per_lane) {
+extern "C" int RT_SCRATCH_NAME(int refract, int count, int ss2, int grid_variant, int one_wave, size_t *bytes_per_lane) {
   const void *f = nullptr;
 #define RT_PICK(R, C, S, G) f = (const void *)&rt_trace<R, C, S, G>
   if (!RT_STRICT && grid_variant && !count) {
 #if !RT_STRICT
-    if (!refract) { if (!ss2) RT_PICK(false, false, false, true); else RT_PICK(false, false, true, true); }
+    if (!refract && one_wave) { if (!ss2) f = (const void *)&rt_trace<false, false, false, true, true>; else f = (const void *)&rt_trace<false, false, true, true, true>; }
+    else if (!refract) { if (!ss2) RT_PICK(false, false, false, true); else RT_PICK(false, false, true, true); }
     else          { if (!ss2) RT_PICK(true, false, false, true);  else RT_PICK(true, false, true, true); }
 #endif
   } else if (!count) {
@@ -1802,6 +1827,16 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
   const dim3 grid(L->grid_x ? L->grid_x : (L->order ? L->tiles_x * L->n_tiles * L->rb_per_tile : L->tiles_x),
                   L->grid_y ? L->grid_y : (L->order ? 1u : L->n_tiles * L->rb_per_tile), L->n_frames), block(RT_WG_THREADS);
 #define RT_CASE(R, C, S, G) hipLaunchKernelGGL((rt_trace<R, C, S, G>), grid, block, lds_bytes, stream, *L)
+#if !RT_STRICT
+  // one-wave workgroups (rt_pixel_of, W1): four per table entry, whole groups of eight entries (the slots behind the last entry are
+  // zero: their workgroups leave at once)
+  if (rt_one_wave_workgroups(false, count != 0, refract != 0, L->cull_in_lds != 0u, L->scatter != 0u)) {
+    const dim3 grid1(((grid.x + 7u) / 8u) * 32u, 1u, L->n_frames), block1(64u);
+    if (!ss2) hipLaunchKernelGGL((rt_trace<false, false, false, true, true>), grid1, block1, lds_bytes, stream, *L);
+    else hipLaunchKernelGGL((rt_trace<false, false, true, true, true>), grid1, block1, lds_bytes, stream, *L);
+    return (int)hipGetLastError();
+  }
+#endif
   // GRID: the shadow-grid variant, a separate instantiation so that scenes with few spheres do not carry its registers
   // (the host leaves the cull rectangles out of the LDS image exactly for the scenes that have a shadow grid or a bounce table)
   const bool grid_variant = !RT_STRICT && !count && !L->cull_in_lds;
