@@ -154,9 +154,9 @@ int scratch_guard(device_state &D, hipStream_t stream, size_t per_lane, uint64_t
 // per-lane scratch of a kernel instantiation, from its code object (asked once per instantiation)
 int kernel_scratch(bool strict, bool retrace, int refract, int count, int ss2, int grid_variant, size_t *out, bool one_wave = false) {
   static std::mutex mu;
-  static size_t cache[3][2][2][2][3];
-  static bool have[3][2][2][2][3];
-  const int k = retrace ? 2 : (strict ? 1 : 0), c = retrace ? 0 : (count ? 1 : 0), g = (retrace || strict) ? 0 : (grid_variant ? (one_wave ? 2 : 1) : 0);
+  static size_t cache[3][2][2][2][4];
+  static bool have[3][2][2][2][4];
+  const int k = retrace ? 2 : (strict ? 1 : 0), c = retrace ? 0 : (count ? 1 : 0), g = (retrace || strict) ? 0 : ((grid_variant ? 1 : 0) + (one_wave ? 2 : 0));
   std::lock_guard<std::mutex> lk(mu);
   if (!have[k][refract ? 1 : 0][c][ss2 ? 1 : 0][g]) {
     size_t b = 0;
@@ -1226,7 +1226,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS - and run one-wave
     // workgroups, rt_device.h, unless they store through the peer-store path)
     if (!strict && !count && !s->cull_in_lds && !s->refract)
-      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, s->cull_in_lds, d_frames != nullptr) ? 64u : RT_WG_THREADS) * 8u;
+      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr) ? 64u : RT_WG_THREADS) * 8u;
+    if (!strict && rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr)) return s->lds_bytes + lds_pad + 10u * 64u * 8u;
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
@@ -1400,7 +1401,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     } else {
     {
       size_t per_lane = 0;
-      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.cull_in_lds != 0u, L.scatter != 0u)))) return rc;
+      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.scatter != 0u)))) return rc;
       if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
     }
 #ifdef RT_WAVE_LOG

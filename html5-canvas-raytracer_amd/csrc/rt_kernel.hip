@@ -1419,20 +1419,22 @@ __device__ __forceinline__ void trace_pixel(const rt_launch &L, const rt_mtl *mt
   rgb[0] = ret[0]; rgb[1] = ret[1]; rgb[2] = ret[2];
 }
 
-// W1: one-wave workgroups (rt_pixel_of), for the reflection-only many-sphere variants - the ones that stage nothing and keep only
-// the fold state in LDS.  A workgroup's waves are placed together: a 4-wave workgroup starts when its CU has room for all four, and
-// where the waves of a launch differ in length - the dear two thirds of a 64-sphere frame: 3 400 - 4 100 of the chip's 5 120 wave
-// slots resident (profiles/wave_timeline.py) - slots wait for their neighbours.  One wave per workgroup fills every slot as it frees:
-// 64 spheres 3840x2160 2x2 -7.6 %, cfg5's frame -6.1 %; kernels that stage an image per workgroup lose (headline +0.5 %, 8K +1.3 %:
-// four times the staging), so they keep four waves (profiles/r04_ab_log.md section 8).  The peer-store path keeps four waves too
-// (it puts whole 128-byte lines together across the workgroup's waves).
+// W1: one-wave workgroups (rt_pixel_of), for the reflection-only variants.  A workgroup's waves are placed together: a 4-wave
+// workgroup starts when its CU has room for all four, and where the waves of a launch differ in length freed slots wait for their
+// neighbours - the dear two thirds of a 64-sphere frame kept 3 400 - 4 100 of the chip's 5 120 wave slots resident, the headline
+// 4 550 - 4 720 (profiles/wave_timeline.py).  One wave per workgroup fills every slot as it frees.  The many-sphere variants stage
+// nothing (64 spheres 2x2 -8.6 %, cfg5's frame -7.1 %); the few-sphere ones stage their image per wave, as 16-byte units - 8 spheres:
+// two loads and two LDS stores per work-item, no barrier (headline -2.8 %, 8K -1.6 %; with the 8-byte staging loop of the four-wave
+// form it was +0.5 %).  The general kernel keeps four waves (its 13-double fold state and image would leave a CU 16 one-wave
+// workgroups), and so does the peer-store path (whole 128-byte lines across the workgroup's waves).  profiles/r04_ab_log.md section 8.
 template <bool REFRACT, bool COUNT, bool SS2, bool GRID, bool W1 = false>
 // Register budget: the reflection-only kernel fits 96 VGPRs = 5 waves per SIMD on its own (measured: 4 waves cost 11 %,
 // more than 5 gain nothing); its shadow-grid variant is held there; the general kernel is left free (forcing it to 5
 // waves spills into its loops: -9 %).
 __global__ void __launch_bounds__(W1 ? 64 : RT_WG_THREADS, ((REFRACT || !GRID) ? RT_WAVES_PER_EU : (RT_WAVES_PER_EU > 5 ? RT_WAVES_PER_EU : 5))) rt_trace(const rt_launch L) {
-  static_assert(!W1 || (GRID && !REFRACT && !COUNT && !RT_STRICT), "one-wave workgroups: the variants that stage nothing");
+  static_assert(!W1 || (!REFRACT && !COUNT && !RT_STRICT), "one-wave workgroups: the reflection-only product variants");
   [[maybe_unused]] constexpr uint32_t WG_WAVES = W1 ? 1u : RT_WG_THREADS / 64u;
+  constexpr uint32_t KT = W1 ? 64u : RT_WG_THREADS;            // work-items of this workgroup
   extern __shared__ double lds_raw[];
 #if defined(RT_WAVE_LOG) && !RT_STRICT
   // measurement build: when this wave started, and where (nothing is kept in registers: the exit stamp recomputes its slot)
@@ -1471,10 +1473,10 @@ __global__ void __launch_bounds__(W1 ? 64 : RT_WG_THREADS, ((REFRACT || !GRID) ?
   [[maybe_unused]] rt_u4 piece[RT_STAGE_PIECES];
   [[maybe_unused]] double stage0 = 0.0;
   if constexpr (!IMAGE_IN_LDS) {
-  } else if constexpr (GRID) {
+  } else if constexpr (GRID || W1) {           // (W1, few spheres: 8 spheres are 112 units - two loads per work-item of the one wave)
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
-    for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) if (i * RT_WG_THREADS < image_vec) piece[i] = image4[tid + i * RT_WG_THREADS];
+    for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) if (i * KT < image_vec) piece[i] = image4[tid + i * KT];
   } else {
     stage0 = (tid < image_words) ? image[tid] : 0.0;
   }
@@ -1539,15 +1541,15 @@ __global__ void __launch_bounds__(W1 ? 64 : RT_WG_THREADS, ((REFRACT || !GRID) ?
 
   // finish the staging (first use of LDS: the cull table or the closest hit's material inside trace_pixel)
   if constexpr (!IMAGE_IN_LDS) {
-  } else if constexpr (GRID) {
+  } else if constexpr (GRID || W1) {
     rt_u4 *lds4 = (rt_u4 *)lds_raw;
     const rt_u4 *__restrict__ image4 = (const rt_u4 *)L.lds_image;
 #pragma unroll
     for (uint32_t i = 0; i < RT_STAGE_PIECES; i++) {
-      const uint32_t k = tid + i * RT_WG_THREADS;
-      if (i * RT_WG_THREADS < image_vec && k < image_vec) lds4[k] = piece[i];
+      const uint32_t k = tid + i * KT;
+      if (i * KT < image_vec && k < image_vec) lds4[k] = piece[i];
     }
-    for (uint32_t k = tid + RT_STAGE_PIECES * RT_WG_THREADS; k < image_vec; k += RT_WG_THREADS) lds4[k] = image4[k];     // more than 73 spheres
+    for (uint32_t k = tid + RT_STAGE_PIECES * KT; k < image_vec; k += KT) lds4[k] = image4[k];     // more than 73 spheres (one-wave workgroups: 17)
   } else {
     if (tid < image_words) lds_raw[tid] = stage0;
     for (uint32_t k = tid + RT_WG_THREADS; k < image_words; k += RT_WG_THREADS) lds_raw[k] = image[k];
@@ -1795,6 +1797,10 @@ extern "C" int RT_SCRATCH_NAME(int refract, int count, int ss2, int grid_variant
     else if (!refract) { if (!ss2) RT_PICK(false, false, false, true); else RT_PICK(false, false, true, true); }
     else          { if (!ss2) RT_PICK(true, false, false, true);  else RT_PICK(true, false, true, true); }
 #endif
+#if !RT_STRICT
+  } else if (!count && !refract && one_wave) {
+    if (!ss2) f = (const void *)&rt_trace<false, false, false, false, true>; else f = (const void *)&rt_trace<false, false, true, false, true>;
+#endif
   } else if (!count) {
     if (!refract) { if (!ss2) RT_PICK(false, false, false, false); else RT_PICK(false, false, true, false); }
     else          { if (!ss2) RT_PICK(true, false, false, false);  else RT_PICK(true, false, true, false); }
@@ -1830,10 +1836,15 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
 #if !RT_STRICT
   // one-wave workgroups (rt_pixel_of, W1): four per table entry, whole groups of eight entries (the slots behind the last entry are
   // zero: their workgroups leave at once)
-  if (rt_one_wave_workgroups(false, count != 0, refract != 0, L->cull_in_lds != 0u, L->scatter != 0u)) {
+  if (rt_one_wave_workgroups(false, count != 0, refract != 0, L->scatter != 0u)) {
     const dim3 grid1(((grid.x + 7u) / 8u) * 32u, 1u, L->n_frames), block1(64u);
-    if (!ss2) hipLaunchKernelGGL((rt_trace<false, false, false, true, true>), grid1, block1, lds_bytes, stream, *L);
-    else hipLaunchKernelGGL((rt_trace<false, false, true, true, true>), grid1, block1, lds_bytes, stream, *L);
+    if (!L->cull_in_lds) {
+      if (!ss2) hipLaunchKernelGGL((rt_trace<false, false, false, true, true>), grid1, block1, lds_bytes, stream, *L);
+      else hipLaunchKernelGGL((rt_trace<false, false, true, true, true>), grid1, block1, lds_bytes, stream, *L);
+    } else {
+      if (!ss2) hipLaunchKernelGGL((rt_trace<false, false, false, false, true>), grid1, block1, lds_bytes, stream, *L);
+      else hipLaunchKernelGGL((rt_trace<false, false, true, false, true>), grid1, block1, lds_bytes, stream, *L);
+    }
     return (int)hipGetLastError();
   }
 #endif

@@ -1489,7 +1489,8 @@ def test_the_general_kernels_scratch_figure_is_what_the_code_object_says(lib):
     fn = lib.rt_scratch_trace_fast
     fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]      # refract, count, ss2, many spheres, one-wave workgroups
     b = C.c_size_t(1)
-    assert fn(0, 0, 0, 0, 0, C.byref(b)) == 0 and b.value == 0          # the headline kernel: no private segment at all
+    assert fn(0, 0, 0, 0, 0, C.byref(b)) == 0 and b.value == 0          # the headline scene's four-wave kernel (peer stores): no private segment at all
+    assert fn(0, 0, 0, 0, 1, C.byref(b)) == 0 and b.value == 0          # ... and the one-wave-workgroup form that renders the headline
     assert fn(0, 0, 1, 1, 0, C.byref(b)) == 0 and b.value <= 16         # cfg5's kernel (one spilled register), its four-wave form
     assert fn(0, 0, 1, 1, 1, C.byref(b)) == 0 and b.value <= 16         # ... and the one-wave-workgroup form that renders cfg5
     assert fn(1, 0, 0, 1, 0, C.byref(b)) == 0 and 0 < b.value <= 4096    # the general kernel: the park stack
