@@ -1222,12 +1222,13 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       memcpy(K.miss_color, s->sky_rgb, sizeof K.miss_color);
     }
   };
+  bool four_waves = false;          // (rt_launch::four_waves: set below, once the launch knows whether it is a camera's first frame)
   auto lds_for = [&](bool strict) {
     // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS - and run one-wave
     // workgroups, rt_device.h, unless they store through the peer-store path)
     if (!strict && !count && !s->cull_in_lds && !s->refract)
-      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr) ? 64u : RT_WG_THREADS) * 8u;
-    if (!strict && rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr)) return s->lds_bytes + lds_pad + 10u * 64u * 8u;
+      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr || four_waves) ? 64u : RT_WG_THREADS) * 8u;
+    if (!strict && rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr || four_waves)) return s->lds_bytes + lds_pad + 10u * 64u * 8u;
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
@@ -1336,6 +1337,10 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
       s->renders_with_camera++;
     }
     const bool masks_pay = L.n_loop <= 16u || uses_before >= 1u;
+    // the first frame from a camera that has moved: a caller that moves the camera every frame has the next camera's table built
+    // beside this launch (rt_scene_set_camera), and that build needs the trace's workgroups to be as wide as its own (rt_launch::four_waves)
+    four_waves = !count && uses_before == 0u && s->cam_gen != 0u;
+    L.four_waves = four_waves ? 1u : 0u;
     // (a table of nothing but sky runs is read by workgroups that store a constant: neither masks nor candidates)
     const bool shadow_masks = !count && !no_shadow_masks && masks_pay && sky_part != 2u && (s->enclosing == ~0u || s->enclosing_flat);
     const bool name_candidates = !count && !no_shadow_masks && sky_part != 2u;
@@ -1401,7 +1406,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     } else {
     {
       size_t per_lane = 0;
-      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.scatter != 0u)))) return rc;
+      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.scatter != 0u || four_waves)))) return rc;
       if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
     }
 #ifdef RT_WAVE_LOG

@@ -121,7 +121,11 @@ struct rt_launch {
   uint32_t retrace_all;              // test build (RT_EXACT_ALL): every sample of the call
   // ... of a compact launch: the table's arrays, from which a sample's block finds its place in the band (rt_tables_gpu.hip: rt_table_emit's arithmetic)
   const uint32_t *tb_item, *tb_rank_in_row, *tb_row_hist, *tb_bin_start;
-  uint32_t tb_bins, tb_pad;
+  uint32_t tb_bins;
+  uint32_t four_waves;               // host side only: this product launch takes the four-wave form of its kernel although it could run one-wave
+                                     // workgroups (rt_one_wave_workgroups): the first frame from a new camera, beside which the NEXT camera's launch
+                                     // table may be built (rt_scene_set_camera) - one-wave workgroups take every slot the moment it frees, and the
+                                     // build's four-wave workgroups would wait for the trace to drain
 #ifdef RT_WAVE_LOG
   // measurement builds only (profiles/ab_build.sh ... "-DRT_WAVE_LOG" hybrid; profiles/wave_timeline.py): per wave of the product launch
   // four words {s_memrealtime at entry, at exit, HW_ID | XCC_ID << 32, workgroup}; NULL = off
