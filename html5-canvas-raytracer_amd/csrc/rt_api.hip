@@ -1227,8 +1227,8 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     // (the reflection-only many-sphere variants keep only the fold state in LDS: rt_kernel.hip, IMAGE_IN_LDS - and run one-wave
     // workgroups, rt_device.h, unless they store through the peer-store path)
     if (!strict && !count && !s->cull_in_lds && !s->refract)
-      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr || four_waves) ? 64u : RT_WG_THREADS) * 8u;
-    if (!strict && rt_one_wave_workgroups(false, count != 0, s->refract, d_frames != nullptr || four_waves)) return s->lds_bytes + lds_pad + 10u * 64u * 8u;
+      return lds_pad + 10u * (rt_one_wave_workgroups(false, count != 0, s->refract, (d_frames != nullptr && !ss2) || four_waves) ? 64u : RT_WG_THREADS) * 8u;
+    if (!strict && rt_one_wave_workgroups(false, count != 0, s->refract, (d_frames != nullptr && !ss2) || four_waves)) return s->lds_bytes + lds_pad + 10u * 64u * 8u;
     return s->lds_bytes + lds_pad + (!strict ? (s->refract ? 13u : 10u) * RT_WG_THREADS * 8u     // + the product kernels' fold state
                                              : RT_WG_THREADS * 8u);                              //   (strict: one slot, the scatter store's tile)
   };
@@ -1406,7 +1406,7 @@ int render_batch_impl(rt_scene_dev *s, uint32_t w, uint32_t h, const rt_tiles *t
     } else {
     {
       size_t per_lane = 0;
-      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, L.scatter != 0u || four_waves)))) return rc;
+      if ((rc = kernel_scratch(false, false, s->refract, count, ss2, !count && !L.cull_in_lds, &per_lane, rt_one_wave_workgroups(false, count != 0, s->refract, (L.scatter != 0u && !ss2) || four_waves)))) return rc;
       if ((rc = scratch_guard(D, stream, per_lane, (uint64_t)L.grid_x * n_frames * (RT_WG_THREADS / 64u), "the trace kernel"))) return rc;
     }
 #ifdef RT_WAVE_LOG

@@ -15,7 +15,8 @@
 #define RT_TILE_W (RT_WG_THREADS / 8)   /* waves side by side, 8 pixels each */
 /* Which product launches run ONE-WAVE workgroups (four per launch-table entry; rt_kernel.hip: W1): the reflection-only variants -
  * the many-sphere ones stage nothing, the few-sphere ones two 16-byte loads per work-item; 10 doubles of fold state per lane -
- * unless the launch stores through the peer-store path, which puts whole 128-byte lines together across a workgroup's four waves.
+ * unless the launch stores through the peer-store path without supersampling, which puts whole 128-byte lines together across a
+ * workgroup's four waves (callers pass `scatter` = "that path": a 2x2 launch stores per wave there too).
  * (The general kernel's 13-double fold state and LDS image would leave a CU 16 one-wave workgroups: it keeps four waves.)
  * Host (LDS size, scratch figure) and launcher ask the same question. */
 static inline bool rt_one_wave_workgroups(bool strict, bool count, bool refract, bool scatter) {

@@ -1836,7 +1836,7 @@ extern "C" int RT_LAUNCH_NAME(const rt_launch *L, int refract, int count, int ss
 #if !RT_STRICT
   // one-wave workgroups (rt_pixel_of, W1): four per table entry, whole groups of eight entries (the slots behind the last entry are
   // zero: their workgroups leave at once)
-  if (rt_one_wave_workgroups(false, count != 0, refract != 0, L->scatter != 0u || L->four_waves != 0u)) {
+  if (rt_one_wave_workgroups(false, count != 0, refract != 0, (L->scatter != 0u && !ss2) || L->four_waves != 0u)) {
     const dim3 grid1(((grid.x + 7u) / 8u) * 32u, 1u, L->n_frames), block1(64u);
     if (!L->cull_in_lds) {
       if (!ss2) hipLaunchKernelGGL((rt_trace<false, false, false, true, true>), grid1, block1, lds_bytes, stream, *L);
