@@ -212,7 +212,7 @@ void rt_scene_free(rt_scene_dev *scene);
  * `rt_scene_set_camera; rt_render_tiles_device; ...` on ONE stream therefore overlaps a frame's table build with its predecessor's
  * trace.  (The one host wait in that loop is bounded: the render that follows a move so closely that the rebuilt table's entry
  * count has not reached the host yet waits for it for at most 0.1 ms + 1 us per 256 blocks - the caller is ahead of the GPU
- * then - and launches one workgroup per block if it does not come.)  `hip_stream` is accepted for source compatibility and not used.  Renders of one scene belong on one stream (several
+ * then - and launches for every block instead of every entry if it does not come.)  `hip_stream` is accepted for source compatibility and not used.  Renders of one scene belong on one stream (several
  * work: a move then drains the device first).  Camera moves and renders of ONE scene handle must not be issued concurrently from
  * different threads (renders among themselves may).  A camera that crosses the scene's enclosing sphere (a skybox) is
  * RT_ERR_UNSUPPORTED: upload the scene again. */
